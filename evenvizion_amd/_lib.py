@@ -1,0 +1,223 @@
+"""ctypes binding of libevhip.so (include/evhip.h).  Host code stays Python; every kernel is reached through this
+thin C-ABI layer.  PyTorch-ROCm is used only to own device memory (tensor.data_ptr()) and for torch.distributed.
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevhip.so")
+
+EVH_SUCCESS = 0
+PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_FEW_MATCHES, PAIR_NO_PROVISIONAL_H, PAIR_LOW_INLIER_RATIO, PAIR_NO_FINAL_H, \
+    PAIR_CAPACITY = range(7)
+MODE_INDEPENDENT_PAIRS, MODE_STREAM = 0, 1
+
+# every symbol include/evhip.h declares, with its ctypes signature
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_pi = C.POINTER(C.c_int)
+SIGNATURES = {
+    "evh_create": (_i, [_i, _i, _i, _i, _i, _vp, C.POINTER(_vp)]),
+    "evh_destroy": (None, [_vp]),
+    "evh_last_error_string": (C.c_char_p, [_vp]),
+    "evh_stream": (_vp, [_vp]),
+    "evh_synchronize": (_i, [_vp]),
+    "evh_version": (_i, []),
+    "evh_resize_area_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp, _i, _i, _i64, _i64]),
+    "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
+    "evh_orb_count": (_i, [_vp, _i]),
+    "evh_orb_capacity": (_i, [_vp]),
+    "evh_orb_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evh_orb_level_info": (_i, [_vp, _i, _pi, _pi, _pi, C.POINTER(C.c_float)]),
+    "evh_orb_download_level": (_i, [_vp, _i, _i, _vp]),
+    "evh_orb_download_candidates": (_i, [_vp, _i, _i, _vp, _i]),
+    "evh_match_knn2_l2u8": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "evh_match_knn2_hamming": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "evh_ratio_unique_filter": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _i, _vp, _pi, _pi]),
+    "evh_find_homography_ransac": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _vp, _pi, _vp]),
+    "evh_static_filter": (_i, [_vp, _vp, _vp, _i, _vp, _pi]),
+    "evh_pair_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp]),
+    "evh_pair_from_slots": (_i, [_vp, _i, _i, _vp, _vp, _pi]),
+    "evh_match_static_from_slots": (_i, [_vp, _i, _i, _vp, _i, _pi, _pi]),
+    "evh_compute_homography": (_i, [_vp, _vp, _i, _vp, _vp, _pi]),
+}
+
+
+class EvhError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libevhip.so for gfx950 with hipcc (evenvizion_amd/csrc/Makefile)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load libevhip.so and bind every declared symbol.  Raises if the library is missing -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EvhError("libevhip.so not found at %s: build it with `make -C evenvizion_amd/csrc` "
+                           "(the HIP library is the only compute backend)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if an include/evhip.h symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _hp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One evh_ctx: one device, one HIP stream, device buffers sized at creation (reused across calls)."""
+
+    def __init__(self, device=0, max_w=1280, max_h=720, max_features=500, max_frames=2, stream=None):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.evh_create(int(device), int(max_w), int(max_h), int(max_features), int(max_frames),
+                                 C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != EVH_SUCCESS:
+            raise EvhError("evh_create failed (%d): %s" % (rc, self.lib.evh_last_error_string(None).decode()))
+        self.h = h
+        self.device = device
+        self.max_frames = max_frames
+        self.max_features = max_features
+        self.max_w, self.max_h = max_w, max_h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.evh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise EvhError("libevhip error %d: %s" % (rc, self.lib.evh_last_error_string(self.h).decode()))
+        return rc
+
+    @property
+    def stream(self):
+        return self.lib.evh_stream(self.h)
+
+    def synchronize(self):
+        self._check(self.lib.evh_synchronize(self.h))
+
+    # ---- K0 ----
+    def resize_area(self, src, dst):
+        """src/dst: CUDA uint8 tensors [n,h,w] or [n,h,w,c], contiguous."""
+        n, sh, sw = src.shape[:3]
+        cn = 1 if src.dim() == 3 else src.shape[3]
+        dh, dw = dst.shape[1:3]
+        self._check(self.lib.evh_resize_area_u8(self.h, src.data_ptr(), n, sw, sh, cn, sw * cn, sw * sh * cn,
+                                                dst.data_ptr(), dw, dh, dw * cn, dw * dh * cn))
+
+    # ---- K1..K6 ----
+    def orb_detect_batch(self, frames, nfeatures=500):
+        """frames: CUDA uint8 tensor [n,h,w] (gray) or [n,h,w,3] (BGR), contiguous."""
+        n, h, w = frames.shape[:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        self._check(self.lib.evh_orb_detect_batch(self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures))
+
+    def orb_download(self, frame):
+        cap = self.lib.evh_orb_capacity(self.h)
+        xy = np.zeros((cap, 2), np.float32); desc = np.zeros((cap, 32), np.uint8)
+        oc = np.zeros(cap, np.int32); lxy = np.zeros((cap, 2), np.int32)
+        rs = np.zeros(cap, np.float32); an = np.zeros(cap, np.float32)
+        n = self._check(self.lib.evh_orb_download(self.h, frame, _hp(xy), _hp(desc), _hp(oc), _hp(lxy), _hp(rs), _hp(an)))
+        return dict(xy=xy[:n].copy(), desc=desc[:n].copy(), octave=oc[:n].copy(), lx=lxy[:n, 0].copy(),
+                    ly=lxy[:n, 1].copy(), response=rs[:n].copy(), angle=an[:n].copy())
+
+    def level_info(self, level):
+        w = C.c_int(); h = C.c_int(); q = C.c_int(); s = C.c_float()
+        self._check(self.lib.evh_orb_level_info(self.h, level, C.byref(w), C.byref(h), C.byref(q), C.byref(s)))
+        return w.value, h.value, q.value, s.value
+
+    def download_level(self, frame, level):
+        w, h, _, _ = self.level_info(level)
+        out = np.zeros((h, w), np.uint8)
+        self._check(self.lib.evh_orb_download_level(self.h, frame, level, _hp(out)))
+        return out
+
+    def download_candidates(self, frame, level):
+        w, h, _, _ = self.level_info(level)
+        cap = (w // 2 + 1) * (h // 2 + 1) + 64
+        buf = np.zeros(cap, np.uint32)
+        n = self._check(self.lib.evh_orb_download_candidates(self.h, frame, level, _hp(buf), cap))
+        p = buf[:min(n, cap)]
+        return (p & 0xFFF).astype(np.int32), ((p >> 12) & 0xFFF).astype(np.int32), (p >> 24).astype(np.int32)
+
+    # ---- K7 + glue ----
+    def knn2(self, q, t, idx, d2, hamming=False):
+        f = self.lib.evh_match_knn2_hamming if hamming else self.lib.evh_match_knn2_l2u8
+        self._check(f(self.h, q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0], idx.data_ptr(), d2.data_ptr()))
+
+    def ratio_unique_filter(self, idx, d2, xy_q, xy_t, pts, ratio=0.5, min_matches=4):
+        n = C.c_int(); st = C.c_int()
+        self._check(self.lib.evh_ratio_unique_filter(self.h, idx.data_ptr(), d2.data_ptr(), idx.shape[0], xy_t.shape[0],
+                                                     xy_q.data_ptr(), xy_t.data_ptr(), float(ratio), int(min_matches),
+                                                     pts.data_ptr(), C.byref(n), C.byref(st)))
+        return n.value, st.value
+
+    # ---- K8/K9 ----
+    def find_homography(self, pts, thr=3.0, max_iters=2000, conf=0.995):
+        n = pts.shape[0]
+        H = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8); info = np.zeros(3, np.int32)
+        found = C.c_int()
+        self._check(self.lib.evh_find_homography_ransac(self.h, pts.data_ptr() if n else None, n, float(thr),
+                                                        int(max_iters), float(conf), _hp(H), _hp(mask), C.byref(found),
+                                                        _hp(info)))
+        return (H.reshape(3, 3) if found.value else None), mask[:n].copy(), info
+
+    def static_filter(self, H, pts, out):
+        H = np.ascontiguousarray(H, np.float64).reshape(9)
+        n = C.c_int()
+        self._check(self.lib.evh_static_filter(self.h, _hp(H), pts.data_ptr(), pts.shape[0], out.data_ptr(), C.byref(n)))
+        return n.value
+
+    # ---- fused ----
+    def pair_homography_batch(self, frames, npairs, mode, out_H, out_status, nfeatures=500, thr=3.0, max_iters=2000,
+                              conf=0.995, force_max_iters=False):
+        h, w = frames.shape[1:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        self._check(self.lib.evh_pair_homography_batch(self.h, frames.data_ptr(), npairs, mode, w, h, cn, w * cn,
+                                                       w * h * cn, nfeatures, float(thr), int(max_iters), float(conf),
+                                                       int(bool(force_max_iters)), out_H.data_ptr(),
+                                                       out_status.data_ptr()))
+
+    def match_static_from_slots(self, cur_slot, prev_slot):
+        cap = self.lib.evh_orb_capacity(self.h)
+        pts = np.zeros((cap, 4), np.float32)
+        n = C.c_int(); st = C.c_int()
+        self._check(self.lib.evh_match_static_from_slots(self.h, cur_slot, prev_slot, _hp(pts), cap, C.byref(n), C.byref(st)))
+        return st.value, pts[:n.value].copy()
+
+    def compute_homography(self, pts, Hsup=None):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
+        H = np.zeros(9, np.float64); st = C.c_int()
+        hs = None if Hsup is None else np.ascontiguousarray(Hsup, np.float64).reshape(9)
+        self._check(self.lib.evh_compute_homography(self.h, _hp(pts), pts.shape[0], _hp(hs), _hp(H), C.byref(st)))
+        return st.value, H.reshape(3, 3)
+
+    def pair_from_slots(self, cur_slot, prev_slot, Hsup=None):
+        H = np.zeros(9, np.float64); st = C.c_int()
+        hs = None if Hsup is None else np.ascontiguousarray(Hsup, np.float64).reshape(9)
+        self._check(self.lib.evh_pair_from_slots(self.h, cur_slot, prev_slot, _hp(hs), _hp(H), C.byref(st)))
+        return st.value, H.reshape(3, 3)

@@ -1,0 +1,479 @@
+// evh_api.hip -- host side of libevhip.so: context, geometry, and the extern "C" entry points of include/evhip.h.
+#include "evh_internal.h"
+#include "evh_match.h"
+#include "evh_ransac.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+static std::string g_create_error;
+
+int evh_fail(evh_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+namespace {
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+inline int64_t align_up64(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline int round_f(float v) { return (int)lrintf(v); }
+
+// ORB_create() defaults: 8 levels, scale factor 1.2f (held as double), per-level size = cvRound(size / scale),
+// per-level quota from the geometric series (orb.cpp); see SURVEY Appendix A.1.
+void compute_geometry(int w, int h, int nfeatures, EvhGeom& g) {
+  g.w = w; g.h = h; g.nfeatures = nfeatures;
+  const double scaleFactor = (double)1.2f;
+  int64_t off = 0, coff = 0;
+  int tiles = 0, tab = 0;
+  for (int l = 0; l < EVH_NLEVELS; l++) {
+    EvhLevel& L = g.lv[l];
+    L.scale = (float)std::pow(scaleFactor, (double)l);
+    L.w = round_f((float)w / L.scale);
+    L.h = round_f((float)h / L.scale);
+    L.stride = align_up(L.w, 64);
+    L.off = off;
+    off += align_up64((int64_t)L.stride * L.h, 256);
+    L.cand_cap = (L.w / 2 + 1) * (L.h / 2 + 1) + 64;  // NMS admits at most one corner per 2x2 block
+    L.cand_off = coff;
+    coff += L.cand_cap;
+    L.tiles_x = (L.w + 63) / 64; L.tiles_y = (L.h + 31) / 32;
+    L.tile_start = tiles;
+    tiles += L.tiles_x * L.tiles_y;
+    L.tab_off = tab;
+    if (l > 0) tab += 2 * L.w + 2 * L.h;
+  }
+  g.pyr_frame_bytes = off;
+  g.cand_frame_entries = coff;
+  g.total_tiles = tiles;
+  const float factor = (float)(1.0 / scaleFactor);
+  float ndes = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)EVH_NLEVELS));
+  int sum = 0;
+  for (int l = 0; l < EVH_NLEVELS - 1; l++) {
+    g.lv[l].quota = round_f(ndes);
+    sum += g.lv[l].quota;
+    ndes *= factor;
+  }
+  g.lv[EVH_NLEVELS - 1].quota = std::max(nfeatures - sum, 0);
+}
+
+// INTER_LINEAR_EXACT coefficient tables for one axis: offset of the left/top tap and the 8.8 weight of the
+// right/bottom tap; samples that fall off either end are encoded as a full weight on the edge sample.
+void linear_exact_tab(int ssize, int dsize, int* ofs, int* c1) {
+  const double inv_scale = (double)dsize / ssize;
+  const double scale = 1.0 / inv_scale;
+  for (int v = 0; v < dsize; v++) {
+    const double fval = scale * ((double)v + 0.5) - 0.5;
+    int ival = (int)std::floor(fval);
+    if (ival >= 0 && ssize > 1) {
+      if (ival < ssize - 1) {
+        ofs[v] = ival;
+        c1[v] = (int)std::lrint((fval - (double)ival) * 256.0);
+      } else { ofs[v] = ssize - 2; c1[v] = 256; }
+    } else { ofs[v] = 0; c1[v] = 0; }
+  }
+}
+
+int kcap_for(int nfeatures) { return align_up(nfeatures + nfeatures / 4 + 64, 64); }
+
+int configure(evh_ctx* c, int w, int h, int nfeatures) {
+  if (c->geom_valid && c->g.w == w && c->g.h == h && c->g.nfeatures == nfeatures) return EVH_SUCCESS;
+  if (w > c->max_w || h > c->max_h || w * (int64_t)h > (int64_t)c->max_w * c->max_h)
+    return evh_fail(c, EVH_ERR_CAPACITY, "frame larger than the size given to evh_create");
+  if (nfeatures > c->max_features || nfeatures < 1)
+    return evh_fail(c, EVH_ERR_CAPACITY, "nfeatures outside [1, max_features]");
+  if (w >= 4096 || h >= 4096) return evh_fail(c, EVH_ERR_UNSUPPORTED, "frames must be smaller than 4096 in each dimension");
+  EvhGeom g;
+  compute_geometry(w, h, nfeatures, g);
+  EvhGeom gmax;
+  compute_geometry(c->max_w, c->max_h, c->max_features, gmax);
+  if (g.pyr_frame_bytes > gmax.pyr_frame_bytes || g.cand_frame_entries > gmax.cand_frame_entries)
+    return evh_fail(c, EVH_ERR_CAPACITY, "geometry exceeds the buffers sized by evh_create");
+  std::vector<int> tabs;
+  for (int l = 1; l < EVH_NLEVELS; l++) {
+    const EvhLevel& S = g.lv[l - 1];
+    const EvhLevel& D = g.lv[l];
+    size_t base = tabs.size();
+    tabs.resize(base + 2 * D.w + 2 * D.h);
+    linear_exact_tab(S.w, D.w, &tabs[base], &tabs[base + D.w]);
+    linear_exact_tab(S.h, D.h, &tabs[base + 2 * D.w], &tabs[base + 2 * D.w + D.h]);
+  }
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  EVH_HIP(c, hipMemcpy(c->d_tabs, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice));
+  c->g = g;
+  c->geom_valid = true;
+  return EVH_SUCCESS;
+}
+
+template <class T>
+int dalloc(evh_ctx* c, T** p, size_t n) {
+  EVH_HIP(c, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  c->bytes_allocated += n * sizeof(T);
+  return EVH_SUCCESS;
+}
+
+EvhRansacArgs pair_ransac_args(evh_ctx* c, double thr, int max_iters, double conf, int force_max) {
+  EvhRansacArgs R{};
+  R.pts = c->d_pts; R.pts2 = c->d_pts2; R.row_stride = c->kcap; R.npts = c->d_npts; R.npts2 = c->d_npts2;
+  R.status = c->d_pstatus; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = force_max;
+  R.mask = c->d_mask; R.crow = c->d_crow; R.lm = c->d_lm; R.H1 = c->d_H1; R.info = c->d_info;
+  return R;
+}
+
+// K7 + glue on resident slots for `npairs` pairs
+int match_pairs(evh_ctx* c, int npairs, int q0, int qstep, int t0, int tstep) {
+  EvhKnnArgs K{};
+  K.q = c->d_desc; K.t = c->d_desc; K.slot_bytes = (int64_t)c->kcap * 32;
+  K.nq_arr = c->d_kp_count; K.nt_arr = c->d_kp_count;
+  K.q_slot0 = q0; K.q_slot_step = qstep; K.t_slot0 = t0; K.t_slot_step = tstep;
+  K.idx = c->d_knn_idx; K.d2 = c->d_knn_d2; K.out_stride = c->kcap; K.hamming = 0;
+  int rc = evh_launch_knn2(c, K, npairs);
+  if (rc) return rc;
+  EvhFilterArgs F{};
+  F.idx = c->d_knn_idx; F.d2 = c->d_knn_d2; F.knn_stride = c->kcap;
+  F.xy_q = c->d_kp_xy; F.xy_t = c->d_kp_xy; F.xy_slot_floats = (int64_t)c->kcap * 2;
+  F.nq_arr = c->d_kp_count; F.nt_arr = c->d_kp_count; F.flags_arr = c->d_frame_flags;
+  F.q_slot0 = q0; F.q_slot_step = qstep; F.t_slot0 = t0; F.t_slot_step = tstep;
+  F.ratio = 0.5; F.min_matches = 4;  // constants.py:25,28 (LOWES_RATIO, MINIMUM_MATCHING_POINTS)
+  F.pts = c->d_pts; F.pts_stride = c->kcap; F.npts = c->d_npts; F.status = c->d_pstatus; F.kcap = c->kcap;
+  return evh_launch_filter(c, F, npairs);
+}
+
+}  // namespace
+
+extern "C" {
+
+int evh_version(void) { return 100; }
+
+const char* evh_last_error_string(const evh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int evh_create(int device, int max_w, int max_h, int max_features, int max_frames, void* stream, evh_ctx** out) {
+  if (!out) return evh_fail(nullptr, EVH_ERR_INVALID, "evh_create: out is NULL");
+  *out = nullptr;
+  if (max_w < 64 || max_h < 64 || max_w >= 4096 || max_h >= 4096 || max_features < 1 || max_frames < 2)
+    return evh_fail(nullptr, EVH_ERR_INVALID, "evh_create: sizes out of range (64 <= w,h < 4096, frames >= 2)");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return evh_fail(nullptr, EVH_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  evh_ctx* c = new evh_ctx();
+  c->device = device; c->max_w = max_w; c->max_h = max_h; c->max_features = max_features; c->max_frames = max_frames;
+  c->kcap = kcap_for(max_features);
+  int rc = EVH_SUCCESS;
+  auto fail = [&](int code) { g_create_error = c->err; evh_destroy(c); return code; };
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { c->err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return fail(EVH_ERR_HIP); }
+    c->own_stream = true;
+  }
+  EvhGeom gmax;
+  compute_geometry(max_w, max_h, max_features, gmax);
+  const size_t F = (size_t)max_frames, K = (size_t)c->kcap;
+  int tabn = 0;
+  for (int l = 1; l < EVH_NLEVELS; l++) tabn += 2 * gmax.lv[l].w + 2 * gmax.lv[l].h;
+#define A_(call) if ((rc = (call)) != EVH_SUCCESS) return fail(rc)
+  A_(dalloc(c, &c->d_pyr, F * (size_t)gmax.pyr_frame_bytes + 256));
+  A_(dalloc(c, &c->d_cand, F * (size_t)gmax.cand_frame_entries));
+  A_(dalloc(c, &c->d_cand_count, F * EVH_NLEVELS));
+  A_(dalloc(c, &c->d_tabs, (size_t)tabn + 64));
+  A_(dalloc(c, &c->d_kp_xy, F * K * 2));
+  A_(dalloc(c, &c->d_kp_meta, F * K));
+  A_(dalloc(c, &c->d_kp_resp, F * K));
+  A_(dalloc(c, &c->d_kp_angle, F * K));
+  A_(dalloc(c, &c->d_desc, F * K * 32));
+  A_(dalloc(c, &c->d_kp_count, F));
+  A_(dalloc(c, &c->d_frame_flags, F));
+  A_(dalloc(c, &c->d_knn_idx, F * K * 2));
+  A_(dalloc(c, &c->d_knn_d2, F * K * 2));
+  A_(dalloc(c, &c->d_pts, F * K * 4));
+  A_(dalloc(c, &c->d_pts2, F * K * 4));
+  A_(dalloc(c, &c->d_crow, F * K * 4));
+  A_(dalloc(c, &c->d_npts, F));
+  A_(dalloc(c, &c->d_npts2, F));
+  A_(dalloc(c, &c->d_pstatus, F));
+  A_(dalloc(c, &c->d_H1, F * 9));
+  A_(dalloc(c, &c->d_mask, F * K));
+  A_(dalloc(c, &c->d_lm, F * K * 4));
+  A_(dalloc(c, &c->d_info, F * 8));
+  A_(dalloc(c, &c->d_small, 64));
+#undef A_
+  e = hipMemset(c->d_kp_count, 0, F * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(c->d_frame_flags, 0, F * sizeof(int));
+  if (e != hipSuccess) { c->err = std::string("hipMemset: ") + hipGetErrorString(e); return fail(EVH_ERR_HIP); }
+  *out = c;
+  return EVH_SUCCESS;
+}
+
+void evh_destroy(evh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+void* evh_stream(const evh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int evh_synchronize(evh_ctx* c) {
+  if (!c) return EVH_ERR_INVALID;
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  return EVH_SUCCESS;
+}
+
+int evh_resize_area_u8(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
+                       int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
+                       int64_t dst_img_stride) {
+  if (!c || !d_src || !d_dst || nimg < 1 || sw < 1 || sh < 1 || dw < 1 || dh < 1 || (cn != 1 && cn != 3))
+    return evh_fail(c, EVH_ERR_INVALID, "evh_resize_area_u8: bad argument");
+  if (nimg > 65535 || dh > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "evh_resize_area_u8: too many images/rows");
+  return evh_launch_resize_area(c, d_src, nimg, sw, sh, cn, src_stride, src_img_stride, d_dst, dw, dh, dst_stride,
+                                dst_img_stride);
+}
+
+int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
+                         int64_t row_stride, int64_t frame_stride, int nfeatures) {
+  if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, "evh_orb_detect_batch: NULL argument");
+  if (nframes < 1 || nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "nframes exceeds max_frames");
+  if (channels != 1 && channels != 3) return evh_fail(c, EVH_ERR_INVALID, "channels must be 1 or 3");
+  if (row_stride < (int64_t)w * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
+  int rc = configure(c, w, h, nfeatures);
+  if (rc) return rc;
+  if ((rc = evh_launch_gray_level0(c, d_frames, nframes, channels, row_stride, frame_stride))) return rc;
+  if ((rc = evh_launch_pyramid(c, nframes))) return rc;
+  if ((rc = evh_launch_fast(c, nframes))) return rc;
+  if ((rc = evh_launch_select(c, nframes))) return rc;
+  if ((rc = evh_launch_describe(c, nframes))) return rc;
+  c->nframes_resident = nframes;
+  return EVH_SUCCESS;
+}
+
+int evh_orb_capacity(const evh_ctx* c) { return c ? c->kcap : EVH_ERR_INVALID; }
+
+int evh_orb_count(evh_ctx* c, int frame) {
+  if (!c || frame < 0 || frame >= c->nframes_resident) return evh_fail(c, EVH_ERR_INVALID, "bad frame slot");
+  int n = 0, fl = 0;
+  EVH_HIP(c, hipMemcpyAsync(&n, c->d_kp_count + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(&fl, c->d_frame_flags + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  if (fl) return evh_fail(c, EVH_ERR_CAPACITY, "a fixed-capacity keypoint list overflowed for this frame");
+  return n;
+}
+
+int evh_orb_download(evh_ctx* c, int frame, float* h_xy, uint8_t* h_desc, int32_t* h_octave, int32_t* h_lxy,
+                     float* h_response, float* h_angle) {
+  int n = evh_orb_count(c, frame);
+  if (n <= 0) return n;
+  const size_t o = (size_t)frame * c->kcap;
+  std::vector<uint32_t> meta;
+  if (h_xy) EVH_HIP(c, hipMemcpyAsync(h_xy, c->d_kp_xy + 2 * o, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+  if (h_desc) EVH_HIP(c, hipMemcpyAsync(h_desc, c->d_desc + 32 * o, 32 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (h_response) EVH_HIP(c, hipMemcpyAsync(h_response, c->d_kp_resp + o, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  if (h_angle) EVH_HIP(c, hipMemcpyAsync(h_angle, c->d_kp_angle + o, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  if (h_octave || h_lxy) {
+    meta.resize(n);
+    EVH_HIP(c, hipMemcpyAsync(meta.data(), c->d_kp_meta + o, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  }
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n && !meta.empty(); i++) {
+    if (h_octave) h_octave[i] = (int32_t)(meta[i] >> 24);
+    if (h_lxy) { h_lxy[2 * i] = (int32_t)(meta[i] & 0xFFFu); h_lxy[2 * i + 1] = (int32_t)((meta[i] >> 12) & 0xFFFu); }
+  }
+  return n;
+}
+
+int evh_orb_level_info(const evh_ctx* c, int level, int* w, int* h, int* quota, float* scale) {
+  if (!c || !c->geom_valid || level < 0 || level >= EVH_NLEVELS) return EVH_ERR_INVALID;
+  const EvhLevel& L = c->g.lv[level];
+  if (w) *w = L.w; if (h) *h = L.h; if (quota) *quota = L.quota; if (scale) *scale = L.scale;
+  return EVH_SUCCESS;
+}
+
+int evh_orb_download_level(evh_ctx* c, int frame, int level, uint8_t* h_pixels) {
+  if (!c || !c->geom_valid || level < 0 || level >= EVH_NLEVELS || frame < 0 || frame >= c->nframes_resident || !h_pixels)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_orb_download_level: bad argument");
+  const EvhLevel& L = c->g.lv[level];
+  EVH_HIP(c, hipMemcpy2DAsync(h_pixels, L.w, c->d_pyr + (size_t)frame * c->g.pyr_frame_bytes + L.off, L.stride, L.w, L.h,
+                              hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  return EVH_SUCCESS;
+}
+
+int evh_orb_download_candidates(evh_ctx* c, int frame, int level, uint32_t* h_packed, int cap) {
+  if (!c || !c->geom_valid || level < 0 || level >= EVH_NLEVELS || frame < 0 || frame >= c->nframes_resident)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_orb_download_candidates: bad argument");
+  const EvhLevel& L = c->g.lv[level];
+  int n = 0;
+  EVH_HIP(c, hipMemcpyAsync(&n, c->d_cand_count + frame * EVH_NLEVELS + level, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  int m = std::min(std::min(n, cap), L.cand_cap);
+  if (m > 0 && h_packed) {
+    EVH_HIP(c, hipMemcpyAsync(h_packed, c->d_cand + (size_t)frame * c->g.cand_frame_entries + L.cand_off,
+                              sizeof(uint32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    EVH_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return n;
+}
+
+static int knn_generic(evh_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, uint32_t* d_d2,
+                       int hamming) {
+  if (!c || !d_idx || !d_d2 || nq < 0 || nt < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_match_knn2: bad argument");
+  if (nq == 0) return EVH_SUCCESS;
+  if (((uintptr_t)d_q | (uintptr_t)d_t) & 15) return evh_fail(c, EVH_ERR_INVALID, "descriptor buffers must be 16-byte aligned");
+  EvhKnnArgs K{};
+  K.q = d_q; K.t = d_t; K.slot_bytes = 0; K.nq_fixed = nq; K.nt_fixed = nt;
+  K.idx = d_idx; K.d2 = d_d2; K.out_stride = nq; K.hamming = hamming;
+  return evh_launch_knn2(c, K, 1);
+}
+
+int evh_match_knn2_l2u8(evh_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, uint32_t* d_d2) {
+  return knn_generic(c, d_q, nq, d_t, nt, d_idx, d_d2, 0);
+}
+int evh_match_knn2_hamming(evh_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
+                           uint32_t* d_d2) {
+  return knn_generic(c, d_q, nq, d_t, nt, d_idx, d_d2, 1);
+}
+
+int evh_ratio_unique_filter(evh_ctx* c, const int32_t* d_idx, const uint32_t* d_d2, int nq, int nt, const float* d_xy_q,
+                            const float* d_xy_t, double ratio, int min_matches, float* d_pts, int* h_count, int* h_status) {
+  if (!c || !d_idx || !d_d2 || !d_xy_q || !d_xy_t || !d_pts || !h_count || !h_status || nq < 0 || nt < 0)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_ratio_unique_filter: bad argument");
+  const int kc = std::max(std::max(nq, nt), 1);
+  if ((size_t)kc * 5 * sizeof(int) > 150 * 1024) return evh_fail(c, EVH_ERR_CAPACITY, "evh_ratio_unique_filter: too many rows");
+  if (((uintptr_t)d_pts) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_pts must be 16-byte aligned");
+  int* d_cnt = reinterpret_cast<int*>(c->d_small);
+  EvhFilterArgs F{};
+  F.idx = d_idx; F.d2 = d_d2; F.knn_stride = nq; F.xy_q = d_xy_q; F.xy_t = d_xy_t; F.xy_slot_floats = 0;
+  F.nq_fixed = nq; F.nt_fixed = nt; F.ratio = ratio; F.min_matches = min_matches;
+  F.pts = d_pts; F.pts_stride = nq; F.npts = d_cnt; F.status = d_cnt + 1; F.kcap = kc;
+  int rc = evh_launch_filter(c, F, 1);
+  if (rc) return rc;
+  int host[2];
+  EVH_HIP(c, hipMemcpyAsync(host, d_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  *h_count = host[0]; *h_status = host[1];
+  return EVH_SUCCESS;
+}
+
+int evh_find_homography_ransac(evh_ctx* c, const float* d_pts, int n, double thr, int max_iters, double conf, double* h_H,
+                               uint8_t* h_mask, int* h_found, int* h_info) {
+  if (!c || (!d_pts && n > 0) || n < 0 || !h_H || !h_found) return evh_fail(c, EVH_ERR_INVALID, "evh_find_homography_ransac: bad argument");
+  if (n > c->kcap * c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "evh_find_homography_ransac: too many rows");
+  if (((uintptr_t)d_pts) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_pts must be 16-byte aligned");
+  // scratch: the per-pair buffers viewed as one big problem
+  EvhRansacArgs R{};
+  R.pts = const_cast<float*>(d_pts); R.n_fixed = n; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = 0;
+  R.mask = c->d_mask; R.crow = c->d_crow; R.lm = c->d_lm;
+  R.H = c->d_small; R.found = reinterpret_cast<int*>(c->d_small + 16); R.info = reinterpret_cast<int*>(c->d_small + 17);
+  int rc = evh_launch_find_homography(c, R);
+  if (rc) return rc;
+  double Hh[9]; int found = 0, info[3] = {0, 0, 0};
+  EVH_HIP(c, hipMemcpyAsync(Hh, c->d_small, sizeof(Hh), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(&found, c->d_small + 16, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(info, c->d_small + 17, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+  if (h_mask && n > 0) EVH_HIP(c, hipMemcpyAsync(h_mask, c->d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(h_H, Hh, sizeof(Hh));
+  *h_found = found;
+  if (h_info) memcpy(h_info, info, sizeof(info));
+  return EVH_SUCCESS;
+}
+
+int evh_static_filter(evh_ctx* c, const double* h_H, const float* d_pts, int n, float* d_out_pts, int* h_count) {
+  if (!c || !h_H || (!d_pts && n > 0) || !d_out_pts || !h_count || n < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_static_filter: bad argument");
+  if (n > c->kcap * c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "evh_static_filter: too many rows");
+  if ((((uintptr_t)d_pts) | ((uintptr_t)d_out_pts)) & 15) return evh_fail(c, EVH_ERR_INVALID, "row buffers must be 16-byte aligned");
+  EVH_HIP(c, hipMemcpyAsync(c->d_small, h_H, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int* d_cnt = reinterpret_cast<int*>(c->d_small + 16);
+  int rc = evh_launch_static_filter(c, c->d_small, d_pts, n, reinterpret_cast<int*>(c->d_lm), d_out_pts, d_cnt);
+  if (rc) return rc;
+  EVH_HIP(c, hipMemcpyAsync(h_count, d_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  return EVH_SUCCESS;
+}
+
+int evh_pair_homography_batch(evh_ctx* c, const uint8_t* d_frames, int npairs, int mode, int w, int h, int channels,
+                              int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
+                              int ransac_max_iters, double ransac_conf, int force_max_iters, double* d_H, int32_t* d_status) {
+  if (!c || !d_frames || !d_H || !d_status || npairs < 1) return evh_fail(c, EVH_ERR_INVALID, "evh_pair_homography_batch: bad argument");
+  if (mode != EVH_MODE_INDEPENDENT_PAIRS && mode != EVH_MODE_STREAM) return evh_fail(c, EVH_ERR_INVALID, "unknown mode");
+  const int nframes = mode == EVH_MODE_INDEPENDENT_PAIRS ? 2 * npairs : npairs + 1;
+  if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "batch needs more frame slots than max_frames");
+  int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
+  if (rc) return rc;
+  if (mode == EVH_MODE_INDEPENDENT_PAIRS) rc = match_pairs(c, npairs, 1, 2, 0, 2);
+  else rc = match_pairs(c, npairs, 1, 1, 0, 1);
+  if (rc) return rc;
+  EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
+  if ((rc = evh_launch_ransac_static(c, R, npairs))) return rc;
+  R.H = d_H; R.out_status = d_status;
+  return evh_launch_ransac_final(c, R, npairs, mode == EVH_MODE_STREAM);
+}
+
+int evh_match_static_from_slots(evh_ctx* c, int cur_slot, int prev_slot, float* h_pts, int cap, int* h_count, int* h_status) {
+  if (!c || !h_count || !h_status || cur_slot < 0 || prev_slot < 0 || cur_slot >= c->nframes_resident ||
+      prev_slot >= c->nframes_resident)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_match_static_from_slots: bad argument");
+  int rc = match_pairs(c, 1, cur_slot, 0, prev_slot, 0);
+  if (rc) return rc;
+  EvhRansacArgs R = pair_ransac_args(c, 3.0, 2000, 0.995, 0);  // constants.py:22 THRESHOLD_FOR_FIND_HOMOGRAPHY
+  if ((rc = evh_launch_ransac_static(c, R, 1))) return rc;
+  int st = 0, n = 0;
+  EVH_HIP(c, hipMemcpyAsync(&st, c->d_pstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(&n, c->d_npts2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  *h_status = st; *h_count = n;
+  if (st == EVH_PAIR_OK && n > 0 && h_pts) {
+    if (n > cap) return evh_fail(c, EVH_ERR_CAPACITY, "h_pts too small");
+    EVH_HIP(c, hipMemcpy(h_pts, c->d_pts2, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  return EVH_SUCCESS;
+}
+
+int evh_compute_homography(evh_ctx* c, const float* h_pts, int n, const double* h_Hsup, double* h_H, int* h_status) {
+  if (!c || (!h_pts && n > 0) || !h_H || !h_status || n < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_compute_homography: bad argument");
+  if (n > c->kcap) return evh_fail(c, EVH_ERR_CAPACITY, "evh_compute_homography: too many rows");
+  const int zero = 0;
+  EVH_HIP(c, hipMemcpyAsync(c->d_pts2, h_pts, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(c->d_npts2, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(c->d_pstatus, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  EvhRansacArgs R = pair_ransac_args(c, 3.0, 2000, 0.995, 0);
+  R.H = c->d_small; R.out_status = reinterpret_cast<int*>(c->d_small + 32);
+  if (h_Hsup) {
+    EVH_HIP(c, hipMemcpyAsync(c->d_small + 16, h_Hsup, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    R.Hsup0 = c->d_small + 16;
+  }
+  // the stream kernel with one pair applies the optional pre-transform; Hprev0 = Hsup0 only marks "not first"
+  R.Hprev0 = R.Hsup0;
+  int rc = evh_launch_ransac_final(c, R, 1, h_Hsup ? 1 : 0);
+  if (rc) return rc;
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  EVH_HIP(c, hipMemcpy(h_H, c->d_small, 9 * sizeof(double), hipMemcpyDeviceToHost));
+  EVH_HIP(c, hipMemcpy(h_status, c->d_small + 32, sizeof(int), hipMemcpyDeviceToHost));
+  return EVH_SUCCESS;
+}
+
+int evh_pair_from_slots(evh_ctx* c, int cur_slot, int prev_slot, const double* h_Hsup, double* h_H, int* h_status) {
+  if (!c || !h_H || !h_status) return evh_fail(c, EVH_ERR_INVALID, "evh_pair_from_slots: bad argument");
+  int n = 0, st = 0;
+  int rc = evh_match_static_from_slots(c, cur_slot, prev_slot, nullptr, 0, &n, &st);
+  if (rc) return rc;
+  if (st != EVH_PAIR_OK) { *h_status = st; memset(h_H, 0, 9 * sizeof(double)); return EVH_SUCCESS; }
+  // static rows are already resident in d_pts2 / d_npts2 / d_pstatus
+  EvhRansacArgs R = pair_ransac_args(c, 3.0, 2000, 0.995, 0);
+  R.H = c->d_small; R.out_status = reinterpret_cast<int*>(c->d_small + 32);
+  if (h_Hsup) {
+    EVH_HIP(c, hipMemcpyAsync(c->d_small + 16, h_Hsup, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    R.Hsup0 = c->d_small + 16; R.Hprev0 = R.Hsup0;
+  }
+  rc = evh_launch_ransac_final(c, R, 1, h_Hsup ? 1 : 0);
+  if (rc) return rc;
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  EVH_HIP(c, hipMemcpy(h_H, c->d_small, 9 * sizeof(double), hipMemcpyDeviceToHost));
+  EVH_HIP(c, hipMemcpy(h_status, c->d_small + 32, sizeof(int), hipMemcpyDeviceToHost));
+  return EVH_SUCCESS;
+}
+
+}  // extern "C"

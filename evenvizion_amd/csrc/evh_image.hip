@@ -1,0 +1,129 @@
+// evh_image.hip -- K0: area-average downscale, the MI355X counterpart of imutils.resize(frame, width=) ->
+// cv2.resize(INTER_AREA) at evenvizion/processing/video_processing.py:62,73.  Shrink only (the reference's
+// "resize_width to speed up" use); equal sizes are a plain copy.  Weights are float32 tables built on the host
+// exactly as the operator builds them; each output value is accumulated in float32 in table order
+// (inner sum over source columns, outer sum over source rows), then rounded half-to-even and saturated.
+#include "evh_internal.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct AreaTabDev {
+  const int* xs; const int* xcnt; const int* xsi; const float* xal;   // per dst column: first entry, count; entries
+  const int* ys; const int* ycnt; const int* ysi; const float* yal;
+};
+
+__global__ void k_resize_area(const uint8_t* __restrict__ src, int cn, int64_t src_stride, int64_t src_img_stride,
+                              uint8_t* __restrict__ dst, int dw, int dh, int64_t dst_stride, int64_t dst_img_stride,
+                              AreaTabDev T) {
+  const int img = blockIdx.z;
+  const int dy = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // dx*cn + c
+  if (e >= dw * cn) return;
+  const int dx = e / cn, c = e - dx * cn;
+  const uint8_t* S = src + (int64_t)img * src_img_stride;
+  const int x0 = T.xs[dx], xn = T.xcnt[dx], y0 = T.ys[dy], yn = T.ycnt[dy];
+  float sum = 0.f;
+  for (int j = 0; j < yn; j++) {
+    const uint8_t* row = S + (int64_t)T.ysi[y0 + j] * src_stride + c;
+    float buf = 0.f;
+    for (int k = 0; k < xn; k++) buf = buf + (float)row[(int64_t)T.xsi[x0 + k] * cn] * T.xal[x0 + k];
+    float term = T.yal[y0 + j] * buf;
+    sum = j == 0 ? term : sum + term;
+  }
+  int v = (int)rintf(sum);
+  dst[(int64_t)img * dst_img_stride + (int64_t)dy * dst_stride + e] = (uint8_t)min(max(v, 0), 255);
+}
+
+__global__ void k_resize_area_int(const uint8_t* __restrict__ src, int cn, int64_t src_stride, int64_t src_img_stride,
+                                  uint8_t* __restrict__ dst, int dw, int dh, int64_t dst_stride, int64_t dst_img_stride,
+                                  int isx, int isy) {
+  const int img = blockIdx.z, dy = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= dw * cn) return;
+  const int dx = e / cn, c = e - dx * cn;
+  const uint8_t* S = src + (int64_t)img * src_img_stride;
+  int sum = 0;
+  for (int j = 0; j < isy; j++)
+    for (int i = 0; i < isx; i++) sum += S[(int64_t)(dy * isy + j) * src_stride + (int64_t)(dx * isx + i) * cn + c];
+  int v;
+  if (isx == 2 && isy == 2) v = (sum + 2) >> 2;
+  else {
+    const float scale = 1.f / (float)(isx * isy);
+    v = (int)rintf((float)sum * scale);
+  }
+  dst[(int64_t)img * dst_img_stride + (int64_t)dy * dst_stride + e] = (uint8_t)min(max(v, 0), 255);
+}
+
+struct HostTab { std::vector<int> start, cnt, si; std::vector<float> al; };
+
+void build_area_tab(int ssize, int dsize, double scale, HostTab& t) {
+  for (int dx = 0; dx < dsize; dx++) {
+    double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    double cell = std::min(scale, ssize - fsx1);
+    int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+    sx2 = std::min(sx2, ssize - 1);
+    sx1 = std::min(sx1, sx2);
+    t.start.push_back((int)t.si.size());
+    if (sx1 - fsx1 > 1e-3) { t.si.push_back(sx1 - 1); t.al.push_back((float)((sx1 - fsx1) / cell)); }
+    for (int sx = sx1; sx < sx2; sx++) { t.si.push_back(sx); t.al.push_back((float)(1.0 / cell)); }
+    if (fsx2 - sx2 > 1e-3) { t.si.push_back(sx2); t.al.push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)); }
+    t.cnt.push_back((int)t.si.size() - t.start.back());
+  }
+}
+
+}  // namespace
+
+int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
+                           int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
+                           int64_t dst_img_stride) {
+  if (dw == sw && dh == sh) {
+    for (int i = 0; i < nimg; i++)
+      EVH_HIP(c, hipMemcpy2DAsync(d_dst + i * dst_img_stride, dst_stride, d_src + i * src_img_stride, src_stride,
+                                  (size_t)sw * cn, sh, hipMemcpyDeviceToDevice, c->stream));
+    return EVH_SUCCESS;
+  }
+  const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+  const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+  if (scale_x < 1 || scale_y < 1)
+    return evh_fail(c, EVH_ERR_UNSUPPORTED, "evh_resize_area_u8: enlarging is outside the hot path");
+  dim3 grid((dw * cn + 255) / 256, dh, nimg);
+  const int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
+  if (std::fabs(scale_x - isx) < 2.220446049250313e-16 && std::fabs(scale_y - isy) < 2.220446049250313e-16) {
+    hipLaunchKernelGGL(k_resize_area_int, grid, dim3(256), 0, c->stream, d_src, cn, src_stride, src_img_stride, d_dst, dw,
+                       dh, dst_stride, dst_img_stride, isx, isy);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
+  HostTab xt, yt;
+  build_area_tab(sw, dw, scale_x, xt);
+  build_area_tab(sh, dh, scale_y, yt);
+  // one device allocation for all eight tables, released after the launch completes
+  const size_t nx = xt.si.size(), ny = yt.si.size();
+  std::vector<int> blob;
+  blob.insert(blob.end(), xt.start.begin(), xt.start.end());
+  blob.insert(blob.end(), xt.cnt.begin(), xt.cnt.end());
+  blob.insert(blob.end(), xt.si.begin(), xt.si.end());
+  for (float f : xt.al) { int v; std::memcpy(&v, &f, 4); blob.push_back(v); }
+  blob.insert(blob.end(), yt.start.begin(), yt.start.end());
+  blob.insert(blob.end(), yt.cnt.begin(), yt.cnt.end());
+  blob.insert(blob.end(), yt.si.begin(), yt.si.end());
+  for (float f : yt.al) { int v; std::memcpy(&v, &f, 4); blob.push_back(v); }
+  int* d_blob = nullptr;
+  EVH_HIP(c, hipMalloc(&d_blob, blob.size() * sizeof(int)));
+  hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size() * sizeof(int), hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { (void)hipFree(d_blob); return evh_fail(c, EVH_ERR_HIP, "resize table upload failed"); }
+  AreaTabDev T;
+  int* p = d_blob;
+  T.xs = p; p += dw; T.xcnt = p; p += dw; T.xsi = p; p += nx; T.xal = reinterpret_cast<float*>(p); p += nx;
+  T.ys = p; p += dh; T.ycnt = p; p += dh; T.ysi = p; p += ny; T.yal = reinterpret_cast<float*>(p);
+  hipLaunchKernelGGL(k_resize_area, grid, dim3(256), 0, c->stream, d_src, cn, src_stride, src_img_stride, d_dst, dw, dh,
+                     dst_stride, dst_img_stride, T);
+  e = hipGetLastError();
+  (void)hipStreamSynchronize(c->stream);  // the pageable upload and the table lifetime both end here
+  (void)hipFree(d_blob);
+  if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("k_resize_area: ") + hipGetErrorString(e));
+  return EVH_SUCCESS;
+}

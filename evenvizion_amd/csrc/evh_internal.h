@@ -1,0 +1,92 @@
+// evh_internal.h -- shared declarations of libevhip.so (host context + kernel launch prototypes).
+// Product code: nothing here (or in any file of this directory) includes or links oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/evhip.h"
+
+#define EVH_NLEVELS 8
+#define EVH_EDGE 31          // ORB edgeThreshold
+#define EVH_FAST_THR 20      // ORB fastThreshold
+#define EVH_K1CAP 8192       // stage-1 (FAST-score) survivors per level held in LDS
+#define EVH_K2CAP 2048       // stage-2 (Harris) survivors per level held in LDS
+
+struct EvhLevel {
+  int w, h, stride;     // stride in bytes (64-byte aligned)
+  int quota;            // nfeaturesPerLevel
+  float scale;          // layerScale
+  int64_t off;          // byte offset inside one frame's pyramid
+  int64_t cand_off;     // entry offset inside one frame's candidate buffer
+  int cand_cap;
+  int tile_start;       // first FAST tile index of this level
+  int tiles_x, tiles_y;
+  int tab_off;          // offset (ints) of the resize tables of this level inside d_tabs
+};
+
+struct EvhGeom {
+  int w, h, nfeatures;
+  EvhLevel lv[EVH_NLEVELS];
+  int64_t pyr_frame_bytes;
+  int64_t cand_frame_entries;
+  int total_tiles;
+};
+
+struct evh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int max_w = 0, max_h = 0, max_features = 0, max_frames = 0;
+  int kcap = 0;  // keypoint rows per frame slot
+  EvhGeom g{};
+  bool geom_valid = false;
+  int nframes_resident = 0;
+  // device buffers
+  uint8_t* d_pyr = nullptr;       // [max_frames][pyr_frame_bytes]
+  uint32_t* d_cand = nullptr;     // [max_frames][cand_frame_entries]
+  int* d_cand_count = nullptr;    // [max_frames][8]
+  int* d_tabs = nullptr;          // resize tables for levels 1..7
+  float* d_kp_xy = nullptr;       // [max_frames][kcap][2]
+  uint32_t* d_kp_meta = nullptr;  // [max_frames][kcap]  level<<24 | y<<12 | x
+  float* d_kp_resp = nullptr;     // [max_frames][kcap]
+  float* d_kp_angle = nullptr;    // [max_frames][kcap]
+  uint8_t* d_desc = nullptr;      // [max_frames][kcap][32]
+  int* d_kp_count = nullptr;      // [max_frames]
+  int* d_frame_flags = nullptr;   // [max_frames] bit0: capacity overflow
+  // pair buffers (max_pairs = max_frames)
+  int32_t* d_knn_idx = nullptr;   // [max_pairs][kcap][2]
+  uint32_t* d_knn_d2 = nullptr;   // [max_pairs][kcap][2]
+  float* d_pts = nullptr;         // [max_pairs][kcap][4] matched rows
+  float* d_pts2 = nullptr;        // [max_pairs][kcap][4] static rows
+  int* d_npts = nullptr;          // [max_pairs]
+  int* d_npts2 = nullptr;         // [max_pairs]
+  int* d_pstatus = nullptr;       // [max_pairs]
+  double* d_H1 = nullptr;         // [max_pairs][9]
+  uint8_t* d_mask = nullptr;      // [max_pairs][kcap]
+  double* d_lm = nullptr;         // [max_pairs][kcap][4] LM per-point temporaries
+  float* d_crow = nullptr;        // [max_pairs][kcap][4] compacted inlier rows
+  int* d_info = nullptr;          // [max_pairs][8]
+  double* d_Hsup = nullptr;       // [9] stream state carried between batches (unused in round 1)
+  double* d_small = nullptr;      // small staging area for single-problem entries (H, counts)
+  size_t bytes_allocated = 0;
+  std::string err;
+};
+
+int evh_fail(evh_ctx* ctx, int code, const std::string& msg);
+#define EVH_HIP(ctx, call)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return evh_fail(ctx, EVH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+// ---- kernel launchers (each enqueues on ctx->stream) ----
+int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int channels, int64_t row_stride,
+                           int64_t frame_stride);
+int evh_launch_pyramid(evh_ctx* c, int nframes);
+int evh_launch_fast(evh_ctx* c, int nframes);
+int evh_launch_select(evh_ctx* c, int nframes);
+int evh_launch_describe(evh_ctx* c, int nframes);
+int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
+                           int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
+                           int64_t dst_img_stride);

@@ -1,0 +1,34 @@
+// evh_match.h -- argument blocks of the matching kernels.  A "slot" is a frame's region inside a batched
+// feature buffer; pair p uses query slot q_slot0 + p*q_slot_step and train slot t_slot0 + p*t_slot_step
+// (independent pairs: 1,2 / 0,2; stream: 1,1 / 0,1; explicit buffers: all zero).
+#pragma once
+#include <stdint.h>
+
+struct EvhKnnArgs {
+  const uint8_t* q; const uint8_t* t;
+  int64_t slot_bytes;             // bytes per descriptor slot
+  const int* nq_arr; const int* nt_arr;  // per-slot counts, or NULL to use the fixed counts
+  int nq_fixed, nt_fixed;
+  int q_slot0, q_slot_step, t_slot0, t_slot_step;
+  int32_t* idx; uint32_t* d2;
+  int64_t out_stride;             // rows per pair in idx / d2
+  int hamming;
+};
+
+struct EvhFilterArgs {
+  const int32_t* idx; const uint32_t* d2;
+  int64_t knn_stride;             // rows per pair in idx / d2
+  const float* xy_q; const float* xy_t;
+  int64_t xy_slot_floats;         // floats per coordinate slot
+  const int* nq_arr; const int* nt_arr; const int* flags_arr;
+  int nq_fixed, nt_fixed;
+  int q_slot0, q_slot_step, t_slot0, t_slot_step;
+  double ratio; int min_matches;
+  float* pts; int64_t pts_stride; // rows per pair
+  int* npts; int* status;
+  int kcap;                       // LDS sizing: >= max(nq, nt)
+};
+
+struct evh_ctx;
+int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs);
+int evh_launch_filter(evh_ctx* c, const EvhFilterArgs& A, int npairs);

@@ -1,0 +1,137 @@
+/*
+ * include/evhip.h -- C ABI of libevhip.so: the MI355X (gfx950) implementation of EvenVizion's
+ * frame-to-frame homography hot path.
+ *
+ * The reference (gridl/EvenVizion) has no FFI of its own: its operator boundary is four third-party calls
+ * made from Python.  Each entry point below names the reference call site it replaces:
+ *
+ *   evh_resize_area_u8            imutils.resize(frame, width=)          video_processing.py:62,73
+ *   evh_orb_detect_batch          cv2.ORB_create().detectAndCompute      frame_processing.py:59-61
+ *   evh_match_knn2_l2u8           DescriptorMatcher("BruteForce").knnMatch(q,t,2)   matching.py:102-108
+ *   evh_ratio_unique_filter       lowes_ratio_test + filter_corresponding_points +
+ *                                 remove_double_matching                 matching.py:112-119,166-239; utils.py:41-68
+ *   evh_find_homography_ransac    cv2.findHomography(a,b,cv2.RANSAC,3.0) matching.py:156-157; utils.py:356-358
+ *   evh_static_filter             find_point_displacement + get_largest_group_points   utils.py:258-325
+ *   evh_pair_homography_batch     the per-pair body of get_homography_dict video_processing.py:67-105
+ *                                 (FrameProcessing.concatenate_all_features_types frame_processing.py:73-108
+ *                                  + compute_homography utils.py:328-363 + matrix_superposition utils.py:118-145)
+ *
+ * Conventions: extern "C", plain pointers and sizes, int return (0 = EVH_SUCCESS, <0 = error; the message is
+ * available from evh_last_error_string), never throws.  Pointers named d_* are DEVICE pointers (hipMalloc /
+ * torch.Tensor.data_ptr()); pointers named h_* are host pointers.  One context is used from one host thread
+ * at a time; multi-GPU = one context (one process) per device.  All work is enqueued on the context's HIP
+ * stream; entry points that fill h_* outputs synchronise that stream before returning, the others do not.
+ */
+#ifndef EVHIP_H
+#define EVHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct evh_ctx evh_ctx;
+
+enum {
+  EVH_SUCCESS = 0,
+  EVH_ERR_INVALID = -1,   /* bad argument                          */
+  EVH_ERR_HIP = -2,       /* a HIP runtime call failed             */
+  EVH_ERR_CAPACITY = -3,  /* exceeds the sizes given to evh_create */
+  EVH_ERR_UNSUPPORTED = -4
+};
+
+/* per-pair status (out_status); mirrors the reference's failure list:
+ *  1 matching.py:104-107 descriptors None   2 matching.py:113 fewer than 4 matches
+ *  3 matching.py:158 provisional H None     4 utils.py:359 inlier ratio < 0.7     5 utils.py:361 H None
+ *  6 an internal fixed-capacity list overflowed for this frame (never silently truncated)             */
+enum {
+  EVH_PAIR_OK = 0,
+  EVH_PAIR_NO_DESCRIPTORS = 1,
+  EVH_PAIR_FEW_MATCHES = 2,
+  EVH_PAIR_NO_PROVISIONAL_H = 3,
+  EVH_PAIR_LOW_INLIER_RATIO = 4,
+  EVH_PAIR_NO_FINAL_H = 5,
+  EVH_PAIR_CAPACITY = 6
+};
+
+enum { EVH_MODE_INDEPENDENT_PAIRS = 0, EVH_MODE_STREAM = 1 };
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+/* stream: a hipStream_t to enqueue on, or NULL to let the context create its own non-blocking stream.          */
+int evh_create(int device, int max_w, int max_h, int max_features, int max_frames, void* stream, evh_ctx** out);
+void evh_destroy(evh_ctx* ctx);
+const char* evh_last_error_string(const evh_ctx* ctx); /* ctx may be NULL: last error of evh_create */
+void* evh_stream(const evh_ctx* ctx);                  /* the hipStream_t all kernels are launched on */
+int evh_synchronize(evh_ctx* ctx);
+int evh_version(void);
+
+/* ---- K0: imutils.resize -> cv2.resize(INTER_AREA), shrink only (identity = copy) --------------------------- */
+/* nimg images of sh x sw x cn uint8 (row stride src_stride bytes, image stride src_img_stride bytes).          */
+int evh_resize_area_u8(evh_ctx* ctx, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
+                       int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
+                       int64_t dst_img_stride);
+
+/* ---- K1..K6: ORB detectAndCompute on a batch of frames ------------------------------------------------------- */
+/* channels: 1 (gray) or 3 (BGR, converted like cvtColor(BGR2GRAY)).  Results stay resident in the context
+ * (frame slots 0..nframes-1) until the next call.                                                              */
+int evh_orb_detect_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, int channels,
+                         int64_t row_stride, int64_t frame_stride, int nfeatures);
+/* number of keypoints of a frame slot, or <0 */
+int evh_orb_count(evh_ctx* ctx, int frame);
+/* capacity (rows) a caller must provide to evh_orb_download */
+int evh_orb_capacity(const evh_ctx* ctx);
+/* copies one frame's features to HOST arrays (any pointer may be NULL): xy f32[n,2] (level-0 pixels, what
+ * the reference keeps from kp.pt), desc u8[n,32], octave i32[n], lxy i32[n,2] (level coordinates),
+ * response f32[n], angle f32[n] (degrees).  Returns n. Canonical order: (octave, y, x).                      */
+int evh_orb_download(evh_ctx* ctx, int frame, float* h_xy, uint8_t* h_desc, int32_t* h_octave, int32_t* h_lxy,
+                     float* h_response, float* h_angle);
+/* test/inspection hooks: pyramid level geometry + contents, FAST candidates (packed score<<24|y<<12|x) */
+int evh_orb_level_info(const evh_ctx* ctx, int level, int* w, int* h, int* quota, float* scale);
+int evh_orb_download_level(evh_ctx* ctx, int frame, int level, uint8_t* h_pixels /* h*w tight */);
+int evh_orb_download_candidates(evh_ctx* ctx, int frame, int level, uint32_t* h_packed, int cap);
+
+/* ---- K7: brute-force 2-NN, L2 over the 32 descriptor bytes (squared distances, exact integers) --------------- */
+/* d_idx i32[nq,2] (-1 = missing neighbour), d_d2 u32[nq,2].  Ties -> lowest train index.                      */
+int evh_match_knn2_l2u8(evh_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
+                        uint32_t* d_d2);
+int evh_match_knn2_hamming(evh_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
+                           uint32_t* d_d2);
+/* ratio test (d0 < d1*ratio on f32 sqrt distances, evaluated in f64), one-to-one filter, duplicate-coordinate
+ * filter.  d_pts f32[nq,4] receives (ax, ay, bx, by) rows; h_count the number of rows; h_status 0 or
+ * EVH_PAIR_FEW_MATCHES.  a = query (current frame), b = train (previous frame).                              */
+int evh_ratio_unique_filter(evh_ctx* ctx, const int32_t* d_idx, const uint32_t* d_d2, int nq, int nt,
+                            const float* d_xy_q, const float* d_xy_t, double ratio, int min_matches, float* d_pts,
+                            int* h_count, int* h_status);
+
+/* ---- K8/K9: findHomography(RANSAC) ---------------------------------------------------------------------------- */
+/* d_pts f32[n,4] rows (ax, ay, bx, by): H maps a -> b.  h_H f64[9], h_mask u8[n] (may be NULL),
+ * h_found 0/1, h_info i32[3] = {ransac iterations, best inlier count, LM iterations} (may be NULL).           */
+int evh_find_homography_ransac(evh_ctx* ctx, const float* d_pts, int n, double thr, int max_iters, double conf,
+                               double* h_H, uint8_t* h_mask, int* h_found, int* h_info);
+/* find_point_displacement + get_largest_group_points: rows of the most populated rounded-displacement bin */
+int evh_static_filter(evh_ctx* ctx, const double* h_H, const float* d_pts, int n, float* d_out_pts, int* h_count);
+
+/* ---- fused batch entry: frames -> H -------------------------------------------------------------------------------- */
+/* mode EVH_MODE_INDEPENDENT_PAIRS: 2*npairs frames laid out (prev0, cur0, prev1, cur1, ...), H_sup = None.
+ * mode EVH_MODE_STREAM: npairs+1 consecutive frames, reference stream semantics (running superposition,
+ * none_H_processing=True: a failed pair repeats the previous H; a failed FIRST pair gets NaNs + its status).
+ * d_H f64[npairs,9] and d_status i32[npairs] are device buffers. Does not synchronise.                        */
+int evh_pair_homography_batch(evh_ctx* ctx, const uint8_t* d_frames, int npairs, int mode, int w, int h,
+                              int channels, int64_t row_stride, int64_t frame_stride, int nfeatures,
+                              double ransac_thr, int ransac_max_iters, double ransac_conf, int force_max_iters,
+                              double* d_H, int32_t* d_status);
+/* the same per-pair body starting from features already resident in the context (frame slots): used by the
+ * Python FrameProcessing/KeyPoints mirror.  cur/prev are frame slots of the last evh_orb_detect_batch.
+ * h_Hsup: f64[9] or NULL.  h_H f64[9]; returns the pair status in *h_status.                                 */
+int evh_pair_from_slots(evh_ctx* ctx, int cur_slot, int prev_slot, const double* h_Hsup, double* h_H,
+                        int* h_status);
+/* KeyPoints.match_static_kps on resident slots: static point rows to host, f32[n,4].                          */
+int evh_match_static_from_slots(evh_ctx* ctx, int cur_slot, int prev_slot, float* h_pts, int cap, int* h_count,
+                                int* h_status);
+/* compute_homography (utils.py:328-363) on host point rows f32[n,4] */
+int evh_compute_homography(evh_ctx* ctx, const float* h_pts, int n, const double* h_Hsup, double* h_H,
+                           int* h_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
