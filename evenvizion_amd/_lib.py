@@ -27,6 +27,9 @@ SIGNATURES = {
     "evh_stream": (_vp, [_vp]),
     "evh_synchronize": (_i, [_vp]),
     "evh_version": (_i, []),
+    "evh_profile_enable": (_i, [_vp, _i]),
+    "evh_profile_read": (_i, [_vp, _vp, _vp]),
+    "evh_profile_stage_name": (C.c_char_p, [_i]),
     "evh_resize_area_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp, _i, _i, _i64, _i64]),
     "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
     "evh_orb_count": (_i, [_vp, _i]),
@@ -65,6 +68,9 @@ def load():
     """Load libevhip.so and bind every declared symbol.  Raises if the library is missing -- there is no fallback."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 and must be loaded FIRST so that
+        # libevhip.so binds to that same runtime (two runtimes in one process cannot both see the device).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise EvhError("libevhip.so not found at %s: build it with `make -C evenvizion_amd/csrc` "
                            "(the HIP library is the only compute backend)" % LIB_PATH)
@@ -119,6 +125,15 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.evh_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.evh_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        """-> {stage: (launch_groups, total_ms)} since the last read (synchronises the stream)."""
+        ms = np.zeros(9, np.float32); cnt = np.zeros(9, np.int32)
+        self._check(self.lib.evh_profile_read(self.h, _hp(ms), _hp(cnt)))
+        return {self.lib.evh_profile_stage_name(i).decode(): (int(cnt[i]), float(ms[i])) for i in range(9)}
 
     # ---- K0 ----
     def resize_area(self, src, dst):

@@ -13,6 +13,24 @@ int evh_fail(evh_ctx* ctx, int code, const std::string& msg) {
   return code;
 }
 
+static hipEvent_t prof_event(evh_ctx* c) {
+  hipEvent_t e = nullptr;
+  if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); return e; }
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+EvhProfScope::EvhProfScope(evh_ctx* ctx, int stage) : c(ctx), idx(-1) {
+  if (!c || !c->profiling) return;
+  evh_ctx::ProfSpan s{stage, prof_event(c), prof_event(c)};
+  if (!s.a || !s.b) return;
+  (void)hipEventRecord(s.a, c->stream);
+  c->prof_spans.push_back(s);
+  idx = (int)c->prof_spans.size() - 1;
+}
+EvhProfScope::~EvhProfScope() {
+  if (idx >= 0) (void)hipEventRecord(c->prof_spans[idx].b, c->stream);
+}
+
 namespace {
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -127,7 +145,8 @@ int match_pairs(evh_ctx* c, int npairs, int q0, int qstep, int t0, int tstep) {
   K.nq_arr = c->d_kp_count; K.nt_arr = c->d_kp_count;
   K.q_slot0 = q0; K.q_slot_step = qstep; K.t_slot0 = t0; K.t_slot_step = tstep;
   K.idx = c->d_knn_idx; K.d2 = c->d_knn_d2; K.out_stride = c->kcap; K.hamming = 0;
-  int rc = evh_launch_knn2(c, K, npairs);
+  int rc;
+  { EvhProfScope ps(c, EVH_ST_KNN); rc = evh_launch_knn2(c, K, npairs); }
   if (rc) return rc;
   EvhFilterArgs F{};
   F.idx = c->d_knn_idx; F.d2 = c->d_knn_d2; F.knn_stride = c->kcap;
@@ -136,6 +155,7 @@ int match_pairs(evh_ctx* c, int npairs, int q0, int qstep, int t0, int tstep) {
   F.q_slot0 = q0; F.q_slot_step = qstep; F.t_slot0 = t0; F.t_slot_step = tstep;
   F.ratio = 0.5; F.min_matches = 4;  // constants.py:25,28 (LOWES_RATIO, MINIMUM_MATCHING_POINTS)
   F.pts = c->d_pts; F.pts_stride = c->kcap; F.npts = c->d_npts; F.status = c->d_pstatus; F.kcap = c->kcap;
+  EvhProfScope ps(c, EVH_ST_FILTER);
   return evh_launch_filter(c, F, npairs);
 }
 
@@ -211,8 +231,35 @@ void evh_destroy(evh_ctx* c) {
                   c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (auto e : c->prof_pool) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+int evh_profile_enable(evh_ctx* c, int on) {
+  if (!c) return EVH_ERR_INVALID;
+  c->profiling = on != 0;
+  return EVH_SUCCESS;
+}
+
+const char* evh_profile_stage_name(int stage) {
+  static const char* names[EVH_NSTAGES] = {"gray", "pyramid", "fast", "select", "describe", "knn2", "filter",
+                                           "ransac_static", "ransac_final"};
+  return stage >= 0 && stage < EVH_NSTAGES ? names[stage] : "";
+}
+
+int evh_profile_read(evh_ctx* c, float* h_total_ms, int* h_counts) {
+  if (!c || !h_total_ms || !h_counts) return evh_fail(c, EVH_ERR_INVALID, "evh_profile_read: bad argument");
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < EVH_NSTAGES; i++) { h_total_ms[i] = 0.f; h_counts[i] = 0; }
+  for (auto& s : c->prof_spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { h_total_ms[s.stage] += ms; h_counts[s.stage]++; }
+    c->prof_pool.push_back(s.a); c->prof_pool.push_back(s.b);
+  }
+  c->prof_spans.clear();
+  return EVH_SUCCESS;
 }
 
 void* evh_stream(const evh_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -241,11 +288,16 @@ int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w
   if (row_stride < (int64_t)w * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
   int rc = configure(c, w, h, nfeatures);
   if (rc) return rc;
-  if ((rc = evh_launch_gray_level0(c, d_frames, nframes, channels, row_stride, frame_stride))) return rc;
-  if ((rc = evh_launch_pyramid(c, nframes))) return rc;
-  if ((rc = evh_launch_fast(c, nframes))) return rc;
-  if ((rc = evh_launch_select(c, nframes))) return rc;
-  if ((rc = evh_launch_describe(c, nframes))) return rc;
+  { EvhProfScope ps(c, EVH_ST_GRAY); rc = evh_launch_gray_level0(c, d_frames, nframes, channels, row_stride, frame_stride); }
+  if (rc) return rc;
+  { EvhProfScope ps(c, EVH_ST_PYRAMID); rc = evh_launch_pyramid(c, nframes); }
+  if (rc) return rc;
+  { EvhProfScope ps(c, EVH_ST_FAST); rc = evh_launch_fast(c, nframes); }
+  if (rc) return rc;
+  { EvhProfScope ps(c, EVH_ST_SELECT); rc = evh_launch_select(c, nframes); }
+  if (rc) return rc;
+  { EvhProfScope ps(c, EVH_ST_DESCRIBE); rc = evh_launch_describe(c, nframes); }
+  if (rc) return rc;
   c->nframes_resident = nframes;
   return EVH_SUCCESS;
 }
@@ -407,8 +459,10 @@ int evh_pair_homography_batch(evh_ctx* c, const uint8_t* d_frames, int npairs, i
   else rc = match_pairs(c, npairs, 1, 1, 0, 1);
   if (rc) return rc;
   EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
-  if ((rc = evh_launch_ransac_static(c, R, npairs))) return rc;
+  { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC); rc = evh_launch_ransac_static(c, R, npairs); }
+  if (rc) return rc;
   R.H = d_H; R.out_status = d_status;
+  EvhProfScope ps(c, EVH_ST_RANSAC_FINAL);
   return evh_launch_ransac_final(c, R, npairs, mode == EVH_MODE_STREAM);
 }
 

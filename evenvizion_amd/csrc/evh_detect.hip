@@ -85,7 +85,10 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b,
 __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
   __shared__ uint32_t tile32[FT_LW * FT_LH / 4];
   __shared__ uint8_t score[FS_W * FS_H + 2];
+  __shared__ uint32_t lst[FT_W * FT_H / 4];  // NMS keeps at most one corner per 2x2 block
+  __shared__ int lcnt, gbase;
   uint8_t* tile = reinterpret_cast<uint8_t*>(tile32);
+  if (threadIdx.x == 0) lcnt = 0;
   int f = blockIdx.y;
   int t = blockIdx.x;
   int l = 0;
@@ -152,9 +155,8 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
   }
   __syncthreads();
   const bool level_ok = (L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE);
-  int* cnt = A.cand_count + f * EVH_NLEVELS + l;
-  uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
-  int lane = threadIdx.x & 63;
+  // NMS + border filter; survivors are collected in LDS, then ONE global atomic per workgroup reserves their slots
+  // (a returning global atomic per wave-iteration serialises on its ~1-2 us latency).
 #pragma unroll 1
   for (int k = 0; k < FT_W * FT_H / 256; k++) {
     int i = threadIdx.x + k * 256;
@@ -162,22 +164,24 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
     int x = x0 + px, y = y0 + py;
     const uint8_t* c = score + (py + 1) * FS_W + (px + 1);
     int s = c[0];
-    bool keep = false;
-    if (s && level_ok && x >= EVH_EDGE && x < L.w - EVH_EDGE && y >= EVH_EDGE && y < L.h - EVH_EDGE)
-      keep = s > c[-1] && s > c[1] && s > c[-FS_W - 1] && s > c[-FS_W] && s > c[-FS_W + 1] && s > c[FS_W - 1] &&
-             s > c[FS_W] && s > c[FS_W + 1];
-    unsigned long long m = __ballot(keep);
-    if (m) {
-      int leader = __ffsll((long long)m) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(cnt, __popcll(m));
-      base = __shfl(base, leader);
+    if (s && level_ok && x >= EVH_EDGE && x < L.w - EVH_EDGE && y >= EVH_EDGE && y < L.h - EVH_EDGE) {
+      bool keep = s > c[-1] && s > c[1] && s > c[-FS_W - 1] && s > c[-FS_W] && s > c[-FS_W + 1] && s > c[FS_W - 1] &&
+                  s > c[FS_W] && s > c[FS_W + 1];
       if (keep) {
-        int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (slot < L.cand_cap) out[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        int slot = atomicAdd(&lcnt, 1);
+        lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
       }
     }
   }
+  __syncthreads();
+  const int n = lcnt;
+  if (n == 0) return;
+  if (threadIdx.x == 0) gbase = atomicAdd(A.cand_count + f * EVH_NLEVELS + l, n);
+  __syncthreads();
+  uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
+  const int base = gbase;
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (base + i < L.cand_cap) out[base + i] = lst[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "../../include/evhip.h"
 
 #define EVH_NLEVELS 8
@@ -70,6 +71,20 @@ struct evh_ctx {
   double* d_small = nullptr;      // small staging area for single-problem entries (H, counts)
   size_t bytes_allocated = 0;
   std::string err;
+  // per-stage timing (evh_profile_*)
+  bool profiling = false;
+  struct ProfSpan { int stage; hipEvent_t a, b; };
+  std::vector<ProfSpan> prof_spans;       // recorded since the last read
+  std::vector<hipEvent_t> prof_pool;      // recycled events
+};
+
+enum { EVH_ST_GRAY = 0, EVH_ST_PYRAMID, EVH_ST_FAST, EVH_ST_SELECT, EVH_ST_DESCRIBE, EVH_ST_KNN, EVH_ST_FILTER,
+       EVH_ST_RANSAC_STATIC, EVH_ST_RANSAC_FINAL };
+// RAII bracket: records an event pair around the launches issued while it is alive (no-op unless profiling)
+struct EvhProfScope {
+  evh_ctx* c; int idx;
+  EvhProfScope(evh_ctx* ctx, int stage);
+  ~EvhProfScope();
 };
 
 int evh_fail(evh_ctx* ctx, int code, const std::string& msg);

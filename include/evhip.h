@@ -64,6 +64,16 @@ void* evh_stream(const evh_ctx* ctx);                  /* the hipStream_t all ke
 int evh_synchronize(evh_ctx* ctx);
 int evh_version(void);
 
+/* ---- per-stage device timing (measurement aid, used by bench.py) ------------------------------------------- */
+/* When enabled, every kernel group launched by the entry points below is bracketed by a pair of hipEvents on
+ * the context's stream.  evh_profile_read synchronises the stream, returns for each stage the number of
+ * bracketed launches-groups and their summed device time in milliseconds since the last read, and resets.
+ * Stage order: gray, pyramid, fast, select, describe, knn2, filter, ransac_static, ransac_final.           */
+#define EVH_NSTAGES 9
+int evh_profile_enable(evh_ctx* ctx, int on);
+int evh_profile_read(evh_ctx* ctx, float* h_total_ms /*[EVH_NSTAGES]*/, int* h_counts /*[EVH_NSTAGES]*/);
+const char* evh_profile_stage_name(int stage);
+
 /* ---- K0: imutils.resize -> cv2.resize(INTER_AREA), shrink only (identity = copy) --------------------------- */
 /* nimg images of sh x sw x cn uint8 (row stride src_stride bytes, image stride src_img_stride bytes).          */
 int evh_resize_area_u8(evh_ctx* ctx, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,

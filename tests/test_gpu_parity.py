@@ -197,7 +197,7 @@ def test_pair_batch_vs_oracle(ctx, w, h, npairs):
             if so[p] == 0:
                 assert h_err(Hg[p], Ho[p]) <= 1e-3
                 assert np.allclose(Hg[p], Ho[p], rtol=1e-9, atol=1e-12)
-                assert corner_err(Hg[p], Ht[p], w, h) < 0.01 * w   # sanity against the analytic ground truth
+                assert corner_err(Hg[p], Ht[p], w, h) < 0.03 * w   # sanity against the analytic ground truth
                 assert corner_err(Hg[p], Ho[p], w, h) <= 0.05
 
 
