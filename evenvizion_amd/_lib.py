@@ -44,6 +44,7 @@ SIGNATURES = {
     "evh_find_homography_ransac": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _vp, _pi, _vp]),
     "evh_static_filter": (_i, [_vp, _vp, _vp, _i, _vp, _pi]),
     "evh_pair_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp]),
+    "evh_stream_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "evh_pair_from_slots": (_i, [_vp, _i, _i, _vp, _vp, _pi]),
     "evh_match_static_from_slots": (_i, [_vp, _i, _i, _vp, _i, _pi, _pi]),
     "evh_compute_homography": (_i, [_vp, _vp, _i, _vp, _vp, _pi]),
@@ -216,6 +217,16 @@ class Context:
                                                        w * h * cn, nfeatures, float(thr), int(max_iters), float(conf),
                                                        int(bool(force_max_iters)), out_H.data_ptr(),
                                                        out_status.data_ptr()))
+
+    def stream_homography_batch(self, frames, out_H, out_status, state_in=None, state_out=None, nfeatures=500, thr=3.0,
+                                max_iters=2000, conf=0.995, force_max_iters=False):
+        """frames: CUDA uint8 [n,h,w(,3)], n >= 2 consecutive frames of one stream -> n-1 pairs (stream semantics)."""
+        n, h, w = frames.shape[:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        self._check(self.lib.evh_stream_homography_batch(
+            self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures, float(thr), int(max_iters), float(conf),
+            int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,
+            state_out.data_ptr() if state_out is not None else None, out_H.data_ptr(), out_status.data_ptr()))
 
     def match_static_from_slots(self, cur_slot, prev_slot):
         cap = self.lib.evh_orb_capacity(self.h)

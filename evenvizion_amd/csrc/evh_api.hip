@@ -466,6 +466,26 @@ int evh_pair_homography_batch(evh_ctx* c, const uint8_t* d_frames, int npairs, i
   return evh_launch_ransac_final(c, R, npairs, mode == EVH_MODE_STREAM);
 }
 
+int evh_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
+                                int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
+                                int ransac_max_iters, double ransac_conf, int force_max_iters, const double* d_state_in,
+                                double* d_state_out, double* d_H, int32_t* d_status) {
+  if (!c || !d_frames || !d_H || !d_status || nframes < 2) return evh_fail(c, EVH_ERR_INVALID, "evh_stream_homography_batch: bad argument");
+  if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "chunk needs more frame slots than max_frames");
+  const int npairs = nframes - 1;
+  int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
+  if (rc) return rc;
+  if ((rc = match_pairs(c, npairs, 1, 1, 0, 1))) return rc;
+  EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
+  { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC); rc = evh_launch_ransac_static(c, R, npairs); }
+  if (rc) return rc;
+  R.H = d_H; R.out_status = d_status;
+  if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
+  R.state_out = d_state_out;
+  EvhProfScope ps(c, EVH_ST_RANSAC_FINAL);
+  return evh_launch_ransac_final(c, R, npairs, 1);
+}
+
 int evh_match_static_from_slots(evh_ctx* c, int cur_slot, int prev_slot, float* h_pts, int cap, int* h_count, int* h_status) {
   if (!c || !h_count || !h_status || cur_slot < 0 || prev_slot < 0 || cur_slot >= c->nframes_resident ||
       prev_slot >= c->nframes_resident)

@@ -14,6 +14,7 @@ struct EvhRansacArgs {
   double thr; int max_iters; double conf; int force_max;
   const double* Hsup0;   // stream mode: superposition entering the batch (NULL = first pair of the stream)
   const double* Hprev0;  // stream mode: previous H entering the batch (NULL = none)
+  double* state_out;     // stream mode: {H_sup, H_prev} after the last pair, f64[18] (may be NULL)
   // scratch
   uint8_t* mask;         // [pair][row_stride]
   float* crow;           // [pair][row_stride][4] compacted inlier rows

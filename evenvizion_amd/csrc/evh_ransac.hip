@@ -842,6 +842,7 @@ __global__ __launch_bounds__(64) void k_ransac_final_stream(EvhRansacArgs A, int
     first = false;
     WSYNC();
   }
+  if (A.state_out && lane < 9) { A.state_out[lane] = Hsup[lane]; A.state_out[9 + lane] = Hprev[lane]; }
 }
 
 }  // namespace

@@ -1,0 +1,51 @@
+"""Process-wide libevhip context cache for the Python mirror of evenvizion.processing.
+
+One process drives one GPU (LOCAL_RANK selects it under torch.distributed.run).  Contexts own all device buffers;
+they are re-created only when a call needs larger frames / more frame slots / more features than the cached one.
+"""
+import os
+
+from . import _lib
+
+_ctx = None
+_cfg = None
+NFEATURES = 500  # cv2.ORB_create() default used by the reference (frame_processing.py:60)
+
+
+def device_index():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def get_context(w, h, nframes=2, nfeatures=NFEATURES):
+    """A context able to hold `nframes` frames of w x h with `nfeatures` keypoints each."""
+    global _ctx, _cfg
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.EvhError("no MI355X visible: evenvizion_amd computes only on the GPU (libevhip.so); "
+                            "there is no CPU fallback")
+    need = (max(int(w), 64), max(int(h), 64), max(int(nframes), 2), int(nfeatures))
+    if _ctx is None or _cfg[0] < need[0] or _cfg[1] < need[1] or _cfg[2] < need[2] or _cfg[3] < need[3]:
+        cfg = need if _cfg is None else tuple(max(a, b) for a, b in zip(_cfg, need))
+        if _ctx is not None:
+            _ctx.close()
+        _ctx = _lib.Context(device=device_index(), max_w=cfg[0], max_h=cfg[1], max_features=cfg[3], max_frames=cfg[2])
+        _cfg = cfg
+    return _ctx
+
+
+def device():
+    import torch
+    return torch.device("cuda", device_index())
+
+
+def to_device(array):
+    import numpy as np
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(array)).to(device())
+
+
+def reset():
+    global _ctx, _cfg
+    if _ctx is not None:
+        _ctx.close()
+    _ctx, _cfg = None, None

@@ -56,12 +56,18 @@ def warp_canvas(canvas, Hmap, w, h, rng=None, noise=2.0):
 def make_pair(seed, w, h, noise=2.0):
     """-> (prev gray u8[h,w], cur gray u8[h,w], H_true) with H_true mapping cur pixels onto prev pixels.
 
-    prev = central crop of the canvas; cur shows canvas at H_true.(x,y) i.e. cur(x) == prev(H_true x)."""
+    Both frames are camera-like views of the canvas (bilinear sampling + sensor noise): prev at a small random
+    pose G0, cur at G0.H_true, so cur(x) == prev(H_true x).  (SURVEY 8d takes prev as the raw central crop; a
+    piecewise-constant axis-aligned crop has NO FAST-9 corner at level 0 -- every ring straddles several blocks --
+    which no real frame resembles, so prev is resampled as well.)"""
     rng = np.random.Generator(np.random.PCG64(seed))
     canvas = make_canvas(rng, w, h)
-    prev = canvas[MARGIN:MARGIN + h, MARGIN:MARGIN + w].copy()
+    th = np.deg2rad(rng.uniform(-2, 2))
+    G0 = np.array([[np.cos(th), -np.sin(th), rng.uniform(-3, 3)], [np.sin(th), np.cos(th), rng.uniform(-3, 3)],
+                   [0, 0, 1]], np.float64)
     Ht = random_h(rng, w)
-    cur = warp_canvas(canvas, Ht, w, h, rng, noise)
+    prev = warp_canvas(canvas, G0, w, h, rng, noise)
+    cur = warp_canvas(canvas, G0 @ Ht, w, h, rng, noise)
     return prev, cur, Ht
 
 
@@ -87,8 +93,9 @@ def make_stream(seed, nframes, w, h, noise=2.0):
     canvas = make_canvas(rng, w, h)
     frames = np.empty((nframes, h, w), np.uint8)
     Hs = np.empty((max(nframes - 1, 0), 3, 3), np.float64)
-    G = np.eye(3)
-    frames[0] = canvas[MARGIN:MARGIN + h, MARGIN:MARGIN + w]
+    th = np.deg2rad(rng.uniform(-2, 2))
+    G = np.array([[np.cos(th), -np.sin(th), 0.4], [np.sin(th), np.cos(th), 0.3], [0, 0, 1]], np.float64)
+    frames[0] = warp_canvas(canvas, G, w, h, rng, noise)
     for k in range(1, nframes):
         Hk = random_h(rng, w)
         # keep the accumulated pose near the canvas centre: mean-reverting translation

@@ -129,6 +129,14 @@ int evh_pair_homography_batch(evh_ctx* ctx, const uint8_t* d_frames, int npairs,
                               int channels, int64_t row_stride, int64_t frame_stride, int nfeatures,
                               double ransac_thr, int ransac_max_iters, double ransac_conf, int force_max_iters,
                               double* d_H, int32_t* d_status);
+/* Stream form with explicit carry-over so that a long video can be processed in chunks: nframes consecutive
+ * frames -> nframes-1 pairs.  d_state_in: f64[18] = {H_sup(9), H_prev(9)} leaving the previous chunk, or NULL for
+ * the first chunk of a stream; d_state_out: f64[18] receives the state after the last pair (may be NULL).
+ * Consecutive chunks overlap by one frame.  Does not synchronise.                                              */
+int evh_stream_homography_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, int channels,
+                                int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
+                                int ransac_max_iters, double ransac_conf, int force_max_iters,
+                                const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status);
 /* the same per-pair body starting from features already resident in the context (frame slots): used by the
  * Python FrameProcessing/KeyPoints mirror.  cur/prev are frame slots of the last evh_orb_detect_batch.
  * h_Hsup: f64[9] or NULL.  h_H f64[9]; returns the pair status in *h_status.                                 */

@@ -240,6 +240,17 @@ def main():
                           max_excluding_last=float(np.max(maxima[:-1])), max_including_last=float(np.max(maxima)),
                           sup_last=np.asarray(sup[keys[-1]]).tolist(), sup_keys=[int(k) for k in keys[:3]] + [int(keys[-1])])
 
+    # ---- N1: fixed_coordinate_system on the reference's own example files -------------------------------------------------
+    import evenvizion.processing.fixed_coordinate_system as fcs
+    oc = utils.read_json_with_coordinates(os.path.join(REF, "evenvizion/examples/test_video/original_coordinates.json"))
+    frames = [1, 2, 60, 121]
+    sub = {k: oc[k] for k in frames}
+    fx = fcs.from_original_to_fix(sub, sup, [658, 1170], [224, 400])
+    back = fcs.from_fix_to_original(fx, sup, [658, 1170], [224, 400])
+    tofloat = lambda d: {str(k): [{kk: float(vv) for kk, vv in r.items()} for r in v] for k, v in d.items()}
+    out["fixed_coordinates"] = dict(frames=frames, original=tofloat(sub), fixed=tofloat(fx), back=tofloat(back),
+                                    original_shape=[658, 1170], resize_shape=[224, 400])
+
     with open(os.path.join(HERE, "glue_goldens.json"), "w") as f:
         json.dump(out, f)
     print("wrote glue_goldens.json", {k: (len(v) if isinstance(v, list) else "dict") for k, v in out.items()})

@@ -228,3 +228,54 @@ def test_resize_area(ctx):
         ctx.resize_area(dev(img[None]), out)
         ctx.synchronize()
         assert np.array_equal(out.cpu().numpy()[0], want)
+
+
+# ---- the Python mirror of evenvizion.processing, end to end on the GPU -----------------------------------------------
+def test_python_api_mirror_vs_oracle():
+    from evenvizion_amd.processing import FrameProcessing, KeyPoints, NoMatchesException, compute_homography, \
+        get_homography_dict, HomographyException
+    from evenvizion_amd import runtime
+    runtime.reset()
+    frames, _ = S.make_stream(9, 6, 400, 224)
+    bgr = S.gray_to_bgr(frames)
+    # per-call API (frame_processing.py / matching.py / utils.py signatures)
+    fa, fb = FrameProcessing(bgr[1]), FrameProcessing(bgr[0])
+    xy, desc = fa.detect_and_describe_features("ORB")
+    o = O.orb_detect(frames[1])
+    assert xy.dtype == np.float32 and desc.dtype == np.uint8 and np.array_equal(xy, o["xy"]) and np.array_equal(desc, o["desc"])
+    with pytest.raises(ValueError):
+        fa.detect_and_describe_features("BRISK")
+    with pytest.raises(NotImplementedError):
+        fa.detect_and_describe_features("SIFT")
+    pa, pb = fa.concatenate_all_features_types(fb)
+    ob = O.orb_detect(frames[0])
+    st, sa, sb = O.match_static(o["xy"], o["desc"], ob["xy"], ob["desc"])
+    assert st == 0 and np.array_equal(np.array(pa), sa) and np.array_equal(np.array(pb), sb)
+    H = compute_homography(pa, pb, None)
+    st2, Ho = O.compute_homography(sa, sb, None)
+    assert st2 == 0 and np.allclose(H, Ho, rtol=1e-9, atol=1e-12)
+    ka, kb = KeyPoints(xy, desc), KeyPoints(ob["xy"], ob["desc"])
+    ma, mb = ka.match_kps(kb)
+    assert len(ma) == len(mb) >= len(sa)
+    with pytest.raises(NoMatchesException):
+        KeyPoints(xy, None).match_kps(kb)
+    with pytest.raises(NoMatchesException):
+        KeyPoints(xy[:3], desc[:3]).match_kps(kb)
+    with pytest.raises(HomographyException):
+        compute_homography(sa[:3], sb[:3])
+    # the driver (video_processing.get_homography_dict), chunked so that state is carried across GPU calls
+    Hs, sts, rc = O.stream_gray(frames)
+    assert rc == -1
+    for chunk in (64, 3):
+        d = get_homography_dict(S.SyntheticCapture(list(bgr)), resize_width=400, chunk_frames=chunk)
+        assert list(d.keys()) == [2, 3, 4, 5, 6, "resize_info"] and d["resize_info"] == {"h": 224, "w": 400}
+        for k in range(2, 7):
+            assert np.allclose(np.array(d[k]["H"]), Hs[k - 2], rtol=1e-9, atol=1e-12)
+    # resize_width smaller than the frame: INTER_AREA on the GPU, then the same path
+    d = get_homography_dict(S.SyntheticCapture(list(bgr)), resize_width=320)
+    small = np.stack([O.bgr2gray(O.resize_area(f, 320, 179)) for f in bgr])
+    Hs2, st2, rc2 = O.stream_gray(small)
+    assert d["resize_info"] == {"h": 179, "w": 320} and rc2 == -1
+    for k in range(2, 7):
+        assert np.allclose(np.array(d[k]["H"]), Hs2[k - 2], rtol=1e-9, atol=1e-12)
+    runtime.reset()

@@ -1,0 +1,166 @@
+"""Host-side mirror of evenvizion.processing (evenvizion_amd/processing) against the golden vectors captured from
+the reference's own functions; these paths are pure host glue and run without a GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from evenvizion_amd.processing import matching, utils, fixed_coordinate_system as fcs, video_processing
+from evenvizion_amd import runtime
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class DMatch:
+    def __init__(self, q, t, d):
+        self.queryIdx, self.trainIdx, self.distance = q, t, d
+
+
+def test_api_surface_matches_reference_exports():
+    import evenvizion_amd.processing as P
+    for name in ["get_homography_dict", "FrameProcessing", "KeyPoints", "NoMatchesException", "lowes_ratio_test",
+                 "filter_corresponding_points", "compute_homography", "HomographyException", "remove_double_matching",
+                 "find_point_displacement", "get_largest_group_points", "homography_transformation",
+                 "inverse_homography_transformation", "matrix_superposition", "read_homography_dict",
+                 "superposition_dict", "are_infinity_coordinates", "read_json_with_coordinates", "from_original_to_fix",
+                 "from_fix_to_original", "LOWES_RATIO", "THRESHOLD_FOR_FIND_HOMOGRAPHY", "MINIMUM_MATCHING_POINTS",
+                 "LENGTH_ACCOUNTED_POINTS", "INFINITY_COORDINATE", "HEATMAP_CONSTANT"]:
+        assert hasattr(P, name), name
+    assert (P.LOWES_RATIO, P.THRESHOLD_FOR_FIND_HOMOGRAPHY, P.MINIMUM_MATCHING_POINTS, P.LENGTH_ACCOUNTED_POINTS) == \
+        (0.5, 3.0, 4, 0.7)
+    e = P.NoMatchesException("why", "what")
+    assert str(e) == "why -> what" and e.reason == "why"
+    assert P.HomographyException().message == "can't calculate homography matrix"
+
+
+def test_lowes_ratio_test(goldens):
+    for c in goldens["lowes_ratio_test"]:
+        raw = [[DMatch(i, int(t), float(np.sqrt(np.float32(d)))) for t, d in zip(ti, di) if t >= 0]
+               for i, (ti, di) in enumerate(zip(c["idx"], c["d2"]))]
+        assert [[t, q] for t, q in matching.lowes_ratio_test(raw, c["ratio"])] == c["matches"]
+
+
+def test_remove_double_and_static_filter(goldens):
+    for c in goldens["remove_double_matching"]:
+        a, b = utils.remove_double_matching(np.float32(c["a"]), np.float32(c["b"]))
+        assert np.array_equal(np.array(a), np.float32(c["out_a"])) and np.array_equal(np.array(b), np.float32(c["out_b"]))
+    for c in goldens["static_filter"]:
+        a, b = np.float32(c["a"]), np.float32(c["b"])
+        g = utils.find_point_displacement(np.array(c["H"]), a, b)
+        assert [int(k) for k in g.keys()] == c["group_order"]
+        assert {str(int(k)): v for k, v in g.items()} == c["groups"]
+        sa, sb = utils.get_largest_group_points(g, a, b)
+        assert np.array_equal(sa, np.float32(c["out_a"]).reshape(-1, 2)) and np.array_equal(sb, np.float32(c["out_b"]).reshape(-1, 2))
+
+
+def test_superposition_and_transform(goldens):
+    for c in goldens["matrix_superposition"]:
+        H, S = np.array(c["H"]), np.array(c["S"])
+        assert np.array_equal(utils.matrix_superposition(H, S, False), np.array(c["sup_false"]))
+        assert np.array_equal(utils.matrix_superposition(H, S, True), np.array(c["sup_true"]))
+        assert utils.homography_transformation(np.float32(c["v"]), H).tolist() == c["hv"]
+
+
+def test_kat_f12_through_the_mirror(goldens):
+    hd, ri = utils.read_homography_dict(os.path.join(GOLD, "ref_dict_with_homography_matrix.json"))
+    sup = utils.superposition_dict(hd)
+    assert list(sup)[:3] == [1, 2, 3] and ri == {"h": 224, "w": 400}
+    ys, xs = np.mgrid[0:224, 0:400].astype(np.float64)
+    mx = []
+    for k, Hk in sup.items():
+        Hk = np.asarray(Hk, np.float64)
+        d = Hk[2, 0] * xs + Hk[2, 1] * ys + Hk[2, 2]
+        mx.append(max(((Hk[0, 0] * xs + Hk[0, 1] * ys + Hk[0, 2]) / d).max(), ((Hk[1, 0] * xs + Hk[1, 1] * ys + Hk[1, 2]) / d).max()))
+    assert max(mx[:-1]) == 863.0428982580879 == float(open(os.path.join(GOLD, "ref_metrics_file.txt")).read().split(":")[1])
+
+
+def test_fixed_coordinates(goldens):
+    g = goldens["fixed_coordinates"]
+    hd, _ = utils.read_homography_dict(os.path.join(GOLD, "ref_dict_with_homography_matrix.json"))
+    sup = utils.superposition_dict(hd)
+    orig = {int(k): v for k, v in g["original"].items()}
+    fx = fcs.from_original_to_fix(orig, sup, g["original_shape"], g["resize_shape"])
+    back = fcs.from_fix_to_original(fx, sup, g["original_shape"], g["resize_shape"])
+    for k in orig:
+        for got, want in zip(fx[k], g["fixed"][str(k)]):
+            assert float(got["x1"]) == want["x1"] and float(got["y1"]) == want["y1"]
+        for got, want in zip(back[k], g["back"][str(k)]):
+            assert float(got["x1"]) == want["x1"] and float(got["y1"]) == want["y1"]
+    assert [fx[1][0]["x1"], fx[1][0]["y1"], fx[1][1]["x1"], fx[1][1]["y1"]] == [121.52, 160.31, 185.79, 80.65]
+
+
+def test_resized_shape_follows_imutils():
+    assert video_processing.resized_shape((658, 1170, 3), 400) == (400, 224)     # the reference example: 224 x 400
+    assert video_processing.resized_shape((720, 1280, 3), 320) == (320, 180)
+    assert video_processing.resized_shape((720, 1280, 3), 1280) == (1280, 720)
+
+
+class _Cap:
+    def __init__(self, n, shape=(6, 12, 3)):
+        self.n, self.i, self.shape = n, 0, shape
+
+    def read(self):
+        if self.i >= self.n:
+            return False, None
+        f = np.full(self.shape, self.i, np.uint8)
+        self.i += 1
+        return True, f
+
+
+class _FakeCtx:
+    """Stands in for libevhip in the host-loop test: plays a scripted per-pair plan with the device kernel's stream
+    semantics (failed pair repeats the previous H; failing first pair -> NaN)."""
+
+    def __init__(self, plan):
+        self.plan, self.prev, self.calls = plan, None, []
+
+    def resize_area(self, src, dst):
+        dst.copy_(src[:, :dst.shape[1], :dst.shape[2]])
+
+    def stream_homography_batch(self, frames, H, st, state_in=None, state_out=None, nfeatures=500, **kw):
+        ids = frames[:, 0, 0, 0].tolist()
+        self.calls.append((ids, state_in is not None))
+        for k in range(1, len(ids)):
+            r = self.plan[str(ids[k])]
+            if isinstance(r, str):
+                st[k - 1] = 2 if r == "nomatch" else 4
+                H[k - 1] = float("nan") if self.prev is None else self.prev
+            else:
+                st[k - 1] = 0
+                self.prev = __import__("torch").tensor(r, dtype=__import__("torch").float64).reshape(9)
+                H[k - 1] = self.prev
+
+    def synchronize(self):
+        pass
+
+
+@pytest.mark.parametrize("chunk", [2, 3, 64])
+def test_driver_loop_matches_reference(goldens, monkeypatch, chunk):
+    import torch
+    monkeypatch.setattr(runtime, "device", lambda: torch.device("cpu"))
+    # the golden run replaced imutils.resize by a plain crop img[:, :width]; mirror that stand-in here
+    monkeypatch.setattr(video_processing, "resized_shape", lambda shape, width: (width, shape[0]))
+    for c in goldens["driver_loop"]["cases"]:
+        fake = _FakeCtx(c["plan"])
+        monkeypatch.setattr(runtime, "get_context", lambda *a, **k: fake)
+        res = video_processing.get_homography_dict(_Cap(c["nframes"]), resize_width=c["resize_width"], chunk_frames=chunk)
+        want = c["result"]
+        assert [str(k) for k in res.keys()] == list(want.keys())          # 2..n then "resize_info" last
+        assert res["resize_info"] == want["resize_info"]
+        for k, v in res.items():
+            if k != "resize_info":
+                assert v == want[str(k)], k
+        assert json.loads(json.dumps(res)) == json.loads(json.dumps(want))
+        # chunks overlap by one frame and only the first has no carried state
+        assert [s for _, s in fake.calls] == [False] + [True] * (len(fake.calls) - 1)
+    # a failing first pair: the reference dies with AttributeError (None.tolist())
+    assert goldens["driver_loop"]["first_pair_failure_exception"] == "AttributeError"
+    fake = _FakeCtx({"1": "nomatch", "2": np.eye(3).tolist()})
+    monkeypatch.setattr(runtime, "get_context", lambda *a, **k: fake)
+    with pytest.raises(AttributeError):
+        video_processing.get_homography_dict(_Cap(3), resize_width=8, chunk_frames=chunk)
+    with pytest.raises(ValueError):
+        video_processing.get_homography_dict(_Cap(0))
+    with pytest.raises(NotImplementedError):
+        video_processing.get_homography_dict(_Cap(3), matching_path="/tmp/x")

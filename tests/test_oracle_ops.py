@@ -1,0 +1,180 @@
+"""Independent checks of the oracle's restated operators (parity with OpenCV itself is unpinned -- no cv2 in the
+image and no vectors in the reference; these tests pin the oracle against definitions, numpy and analytic truth)."""
+import math
+
+import numpy as np
+import pytest
+
+from evenvizion_amd import synthetic as S
+from oracle import oracle as O
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0),
+        (-3, 1), (-2, 2), (-1, 3)]
+
+
+def fast_by_definition(img, thr):
+    """FAST-9/16 straight from its definition: corner, score = largest t keeping it a corner, 3x3 NMS."""
+    h, w = img.shape
+    sc = np.zeros((h, w), np.int32)
+    I = img.astype(np.int32)
+
+    def is_corner(y, x, t):
+        v = I[y, x]
+        r = [I[y + dy, x + dx] for dx, dy in RING]
+        for sign in (1, -1):
+            flags = [(sign * (p - v)) > t for p in r] * 2
+            run = 0
+            for f in flags:
+                run = run + 1 if f else 0
+                if run >= 9:
+                    return True
+        return False
+
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if is_corner(y, x, thr):
+                t = thr
+                while is_corner(y, x, t + 1):
+                    t += 1
+                sc[y, x] = t
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = sc[y, x]
+            if s and all(s > sc[y + j, x + i] for j in (-1, 0, 1) for i in (-1, 0, 1) if (i, j) != (0, 0)):
+                out.append((x, y, int(s)))
+    return out
+
+
+def test_fast_matches_definition():
+    img = np.ascontiguousarray(S.make_pair(3, 400, 224)[1][40:110, 60:150])
+    xs, ys, sc = O.fast_nms(img, 20)
+    assert len(xs) > 20
+    assert sorted(zip(xs.tolist(), ys.tolist(), sc.tolist())) == sorted(fast_by_definition(img, 20))
+
+
+def test_sincos_float_results_equal_libm():
+    worst = 0.0
+    for deg in np.linspace(0, 360, 200001, dtype=np.float32):
+        rad = np.float32(deg * np.float32(math.pi / np.float32(180.0)))
+        s, c = O.sincos(float(rad))
+        worst = max(worst, abs(s - math.sin(float(rad))), abs(c - math.cos(float(rad))))
+        assert np.float32(s) == np.float32(math.sin(float(rad))) and np.float32(c) == np.float32(math.cos(float(rad)))
+    assert worst < 4e-16
+
+
+def test_fast_atan2_accuracy():
+    for y, x in [(0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (3, 4), (-5, 2), (1e5, 3)]:
+        want = math.degrees(math.atan2(y, x)) % 360
+        assert abs(O.fast_atan2(y, x) - want) < 0.3
+
+
+def test_layout_matches_survey_tables():
+    lw, lh, ls, lq = O.orb_layout(1280, 720, 500)
+    assert list(zip(lw, lh)) == [(1280, 720), (1067, 600), (889, 500), (741, 417), (617, 347), (514, 289), (429, 241), (357, 201)]
+    assert lq.tolist() == [109, 90, 75, 63, 52, 44, 36, 31]
+    assert O.orb_layout(1280, 720, 2000)[3].tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert O.orb_layout(3840, 2160, 4000)[3].tolist() == [869, 724, 603, 503, 419, 349, 291, 242]
+
+
+def test_linear_exact_resize_properties():
+    flat = np.full((50, 70), 93, np.uint8)
+    assert (O.resize_linear_exact(flat, 58, 42) == 93).all()
+    ramp = np.tile(np.arange(0, 240, 2, dtype=np.uint8), (60, 1))       # horizontal ramp stays monotone
+    r = O.resize_linear_exact(ramp, 100, 50)
+    assert (np.diff(r.astype(int), axis=1) >= 0).all() and (r[0] == r[-1]).all()
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    half = O.resize_linear_exact(img, 32, 32)                            # exact 2:1 = mean of 2x2 with rounding
+    want = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.abs(half.astype(int) - want).max() <= 1
+
+
+def test_area_resize_properties():
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    assert np.array_equal(O.resize_area(img, 80, 60), img)                                # identity = copy
+    q = O.resize_area(img, 20, 15)                                                        # integer 4x4 -> block mean
+    want = img.reshape(15, 4, 20, 4, 3).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(q - want).max() <= 0.5 + 1e-9
+    g = O.resize_area(np.full((658, 1170), 201, np.uint8), 400, 224)                     # the reference's geometry
+    assert g.shape == (224, 400) and (g == 201).all()
+    with pytest.raises(NotImplementedError):
+        O.resize_area(img, 160, 120)
+
+
+def test_gaussian_blur_kernel():
+    imp = np.zeros((21, 21), np.uint8); imp[10, 10] = 255
+    b = O.gaussian_blur7(imp).astype(int)
+    k = np.array([18, 34, 49, 55, 49, 34, 18])
+    want = (np.outer(k, k) * 255 + 32768) >> 16
+    assert np.array_equal(b[7:14, 7:14], want)
+    assert (O.gaussian_blur7(np.full((30, 30), 100, np.uint8)) == ((257 * 257 * 100 + 32768) >> 16)).all()
+
+
+def test_jacobi_against_numpy():
+    rng = np.random.default_rng(2)
+    for n in (8, 9):
+        M = rng.normal(size=(n, n)); A = M @ M.T
+        W, V = O.jacobi(A)
+        assert np.all(np.diff(W) <= 1e-12)
+        assert np.allclose(np.sort(W), np.linalg.eigvalsh(A), rtol=1e-10, atol=1e-10)
+        assert np.allclose(V @ V.T, np.eye(n), atol=1e-12)
+        assert np.allclose(V @ A @ V.T, np.diag(W), atol=1e-9)
+
+
+def test_dlt_and_ransac_recover_ground_truth():
+    rng = np.random.default_rng(5)
+    Ht = S.random_h(rng, 400)
+    a = rng.uniform(0, 400, (200, 2))
+    p = (Ht @ np.c_[a, np.ones(200)].T).T
+    b = p[:, :2] / p[:, 2:]
+    H = O.dlt(a, b)
+    assert np.allclose(H / H[2, 2], Ht / Ht[2, 2], rtol=0, atol=2e-4)   # float32 inputs
+    bn = b + rng.normal(0, 0.3, b.shape)
+    out = rng.choice(200, 60, replace=False)
+    bn[out] = rng.uniform(0, 400, (60, 2))
+    H, mask, info = O.find_homography(a, bn)
+    assert H is not None and mask[out].sum() <= 3 and mask.sum() >= 130
+    c = np.array([[0, 0, 1], [400, 0, 1], [0, 224, 1], [400, 224, 1]], float).T
+    pa = H @ c; pb = Ht @ c
+    assert np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max() < 0.5
+    assert info[0] < 50 and info[2] >= 1                                # adaptive stop, LM ran
+    H4, m4, _ = O.find_homography(a[:4], b[:4])
+    assert m4.tolist() == [1, 1, 1, 1] and np.allclose(H4 / H4[2, 2], Ht / Ht[2, 2], atol=1e-3)
+    assert O.find_homography(a[:3], b[:3])[0] is None
+    line = np.c_[np.arange(20.), np.arange(20.)]
+    assert O.find_homography(line, line)[0] is None                      # every sample collinear -> no model
+
+
+def test_knn2_bruteforce_and_ties():
+    rng = np.random.default_rng(6)
+    q = rng.integers(0, 256, (40, 32), dtype=np.uint8); t = rng.integers(0, 256, (55, 32), dtype=np.uint8)
+    t[9] = t[2]; q[0] = t[2]
+    idx, d2 = O.knn2(q, t)
+    D = ((q[:, None, :].astype(int) - t[None].astype(int)) ** 2).sum(-1)
+    order = np.argsort(D, axis=1, kind="stable")[:, :2]
+    assert np.array_equal(idx, order) and np.array_equal(d2, np.take_along_axis(D, order, 1))
+    assert idx[0].tolist() == [2, 9]
+    i1, _ = O.knn2(q, t[:1])
+    assert (i1[:, 1] == -1).all()
+
+
+def test_pair_and_stream_semantics():
+    prev, cur, Ht = S.make_pair(2000, 400, 224)
+    st, H = O.pair_gray(cur, prev)
+    assert st == 0
+    c = np.array([[0, 0, 1], [400, 0, 1], [0, 224, 1], [400, 224, 1]], float).T
+    pa = H @ c; pb = Ht @ c
+    assert np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max() < 8.0
+    flat = np.full((224, 400), 50, np.uint8)
+    assert O.pair_gray(flat, flat)[0] == O.NO_DESCRIPTORS
+    frames, _ = S.make_stream(5, 4, 400, 224)
+    Hs, sts, rc = O.stream_gray(frames)
+    assert rc == -1 and sts.tolist() == [0, 0, 0]
+    bad = frames.copy(); bad[2] = 50                                     # a flat frame in the middle: 2 failing pairs
+    Hs2, st2, rc2 = O.stream_gray(bad)
+    assert rc2 == -1 and st2.tolist() == [0, 1, 1]
+    assert np.array_equal(Hs2[1], Hs2[0]) and np.array_equal(Hs2[2], Hs2[0])   # none_H_processing: previous H
+    bad0 = frames.copy(); bad0[0] = 50
+    assert O.stream_gray(bad0)[2] == 0                                   # failing FIRST pair: the reference raises

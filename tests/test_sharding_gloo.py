@@ -1,0 +1,55 @@
+"""world_size-2 rehearsal of the multi-GPU path on CPU (gloo): pairs are sharded in contiguous blocks, each rank
+fills its block, one all_gather of fixed-size records rebuilds the global (H, status) arrays on every rank."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from evenvizion_amd.sharding import gather_pair_records, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 256, 1001):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_total, rank, world)
+    g = torch.Generator().manual_seed(1234)
+    H_all = torch.randn(n_total, 9, dtype=torch.float64, generator=g)
+    st_all = torch.randint(0, 6, (n_total,), dtype=torch.int32, generator=g)
+    H, st = gather_pair_records(H_all[lo:hi].clone(), st_all[lo:hi].clone(), n_total)
+    ok = bool(torch.equal(H, H_all) and torch.equal(st, st_all))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pair_records_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_single_process_passthrough():
+    H = torch.zeros(3, 9, dtype=torch.float64); st = torch.zeros(3, dtype=torch.int32)
+    H2, st2 = gather_pair_records(H, st, 3)
+    assert H2.shape == (3, 9) and torch.equal(st2, st)
