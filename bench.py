@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=256, help="independent frame pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=1024, help="independent frame pairs per step per GPU")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic pairs generated (tiled to --pairs)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
@@ -87,10 +87,13 @@ def main():
 
     w, h, B = args.width, args.height, args.pairs
     # synthetic frames, a few unique pairs tiled to the batch; every copy is its own HBM region
-    gray, Htrue = synthetic.make_pair_batch(2, B, w, h, unique=min(args.unique, B))
+    U = min(args.unique, B)
+    gray, Htrue = synthetic.make_pair_batch(2, U, w, h)
     host = gray if args.channels == 1 else synthetic.gray_to_bgr(gray)
-    frames = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
-    del host
+    uniq = torch.from_numpy(np.ascontiguousarray(host)).to(dev)            # [2U, h, w(,3)]
+    reps = -(-B // U)
+    frames = uniq.repeat((reps,) + (1,) * (uniq.dim() - 1))[:2 * B].contiguous()   # physical copies in HBM
+    del host, uniq
 
     stream = torch.cuda.Stream(device=dev)
     ctx = Context(device=local_rank, max_w=w, max_h=h, max_features=args.nfeatures, max_frames=2 * B,
@@ -164,8 +167,9 @@ def main():
         from oracle import oracle as O
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cores = min(cores, 16)   # the GPU box's CPU share for one GPU
-        n_s = args.cpu_pairs if args.cpu_pairs > 0 else min(B, 32)
-        sample = np.ascontiguousarray(gray[:2 * n_s])
+        n_s = args.cpu_pairs if args.cpu_pairs > 0 else min(B, 64)
+        idx = np.arange(2 * n_s) % (2 * U)                                   # the batch's first n_s pairs
+        sample = np.ascontiguousarray(gray[idx])
         O.lib()
         t0 = time.perf_counter()
         Ho, so = O.pairs_gray_batch(sample, nfeatures=args.nfeatures, threads=cores)
@@ -187,7 +191,7 @@ def main():
             "config": {"workload": "synthetic %dx%d %s pair batch, %d independent pairs/step/GPU, ORB %d kp, "
                                    "RANSAC max 2000 conf 0.995 (BASELINE.json configs[1])"
                                    % (w, h, "BGR" if args.channels == 3 else "gray", B, args.nfeatures),
-                       "pairs_per_step_per_gpu": B, "unique_pairs": min(args.unique, B), "parallelism": "pairs sharded, dp%d" % world,
+                       "pairs_per_step_per_gpu": B, "unique_pairs": U, "parallelism": "pairs sharded, dp%d" % world,
                        "pairs_ok_fraction": ok_frac,
                        "arithmetic": "u8/i32 pixels+descriptors, f32 Harris+reprojection, f64 DLT+LM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

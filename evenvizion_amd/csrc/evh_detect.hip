@@ -8,19 +8,34 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------------------
 // K1: BGR -> gray (Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14) or gray copy, into pyramid level 0.
-// One thread = 4 output pixels (one dword store); grid.y = frame.
+// One thread = 4 output pixels: three aligned dword loads (12 BGR bytes) -> one dword store; grid.y = frame.
 __global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int64_t row_stride, int64_t frame_stride,
-                              uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int w, int h, int dst_stride) {
-  int f = blockIdx.y;
-  int qpr = (w + 3) >> 2;
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
+                              uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int w, int h, int dst_stride,
+                              int aligned4) {
+  const int f = blockIdx.y;
+  const int qpr = (w + 3) >> 2;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= qpr * h) return;
-  int y = q / qpr, x = (q - y * qpr) * 4;
+  const int y = q / qpr, x = (q - y * qpr) * 4;
   const uint8_t* s = src + (int64_t)f * frame_stride + (int64_t)y * row_stride + (int64_t)x * channels;
   uint8_t* d = pyr + (int64_t)f * pyr_frame_bytes + (int64_t)y * dst_stride + x;
   uint32_t out = 0;
-  int n = min(4, w - x);
-  if (channels == 1) {
+  const int n = min(4, w - x);
+  if (aligned4 && n == 4) {
+    if (channels == 1) out = *reinterpret_cast<const uint32_t*>(s);
+    else {
+      const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+      const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];           // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+      const uint32_t b0 = w0 & 0xFF, g0 = (w0 >> 8) & 0xFF, r0 = (w0 >> 16) & 0xFF;
+      const uint32_t b1 = w0 >> 24, g1 = w1 & 0xFF, r1 = (w1 >> 8) & 0xFF;
+      const uint32_t b2 = (w1 >> 16) & 0xFF, g2 = w1 >> 24, r2 = w2 & 0xFF;
+      const uint32_t b3 = (w2 >> 8) & 0xFF, g3 = (w2 >> 16) & 0xFF, r3 = w2 >> 24;
+      out = ((b0 * 1868u + g0 * 9617u + r0 * 4899u + 8192u) >> 14) |
+            (((b1 * 1868u + g1 * 9617u + r1 * 4899u + 8192u) >> 14) << 8) |
+            (((b2 * 1868u + g2 * 9617u + r2 * 4899u + 8192u) >> 14) << 16) |
+            (((b3 * 1868u + g3 * 9617u + r3 * 4899u + 8192u) >> 14) << 24);
+    }
+  } else if (channels == 1) {
     for (int i = 0; i < n; i++) out |= (uint32_t)s[i] << (8 * i);
   } else {
     for (int i = 0; i < n; i++) {
@@ -35,28 +50,68 @@ __global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int
 // K2: pyramid level l from level l-1, resize(INTER_LINEAR_EXACT): 8.8 fixed-point weights per axis,
 // out = ((c0*s00 + c1*s01)*m0 + (c0*s10 + c1*s11)*m1 + 32768) >> 16.  Tables (host-computed): per dst column
 // (xofs, xc1), per dst row (yofs, yc1); edge replication is encoded in the tables.
-__global__ void k_pyr_down(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t src_off, int src_stride,
-                           int64_t dst_off, int dst_stride, int dw, int dh, const int* __restrict__ xofs,
-                           const int* __restrict__ xc1, const int* __restrict__ yofs, const int* __restrict__ yc1) {
-  int f = blockIdx.y;
-  int qpr = (dw + 3) >> 2;
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= qpr * dh) return;
-  int y = q / qpr, x = (q - y * qpr) * 4;
-  const uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;
-  const uint8_t* r0 = base + src_off + (int64_t)yofs[y] * src_stride;
-  const uint8_t* r1 = r0 + src_stride;
-  uint32_t m1 = (uint32_t)yc1[y], m0 = 256u - m1;
-  uint32_t out = 0;
-  int n = min(4, dw - x);
-  for (int i = 0; i < n; i++) {
-    int o = xofs[x + i];
-    uint32_t c1 = (uint32_t)xc1[x + i], c0 = 256u - c1;
-    uint32_t h0 = c0 * r0[o] + c1 * r0[o + 1];
-    uint32_t h1 = c0 * r1[o] + c1 * r1[o + 1];
-    out |= ((h0 * m0 + h1 * m1 + 32768u) >> 16) << (8 * i);
+// Workgroup = 128 x 16 output pixels; the source footprint (<= 160 x 22 bytes at scale 1.2) is staged in LDS with
+// coalesced dword loads, each thread then produces 2 rows x 4 pixels from LDS bytes and stores one dword per row.
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {   // a*b + c, a,b < 2^24 (half-rate VALU;
+  uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;   // v_mul_lo_u32 / v_mad_u64_u32 are far slower)
+}
+#define PD_W 128
+#define PD_H 16
+#define PD_SW 168   // staged source row bytes (multiple of 4, >= 1.2*128 + 6)
+#define PD_SH 24    // staged source rows (>= 1.2*16 + 3)
+__global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t src_off,
+                                                  int src_stride, int sw, int sh, int64_t dst_off, int dst_stride, int dw,
+                                                  int dh, int tiles_x, const int* __restrict__ xofs,
+                                                  const int* __restrict__ xc1, const int* __restrict__ yofs,
+                                                  const int* __restrict__ yc1) {
+  __shared__ uint32_t tile32[PD_SH * PD_SW / 4];
+  const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
+  const int f = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int x0 = tx * PD_W, y0 = ty * PD_H;
+  const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PD_H, dh) - 1;
+  const int sx0 = xofs[x0] & ~3, sy0 = yofs[y0];
+  const int ncol4 = (xofs[x1] + 1 - sx0) / 4 + 1, nrow = yofs[y1] + 2 - sy0;   // <= PD_SW/4, <= PD_SH
+  uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;   // wave-uniform 64-bit bases; per-lane offsets stay 32-bit
+  const uint8_t* simg = base + src_off + sx0;
+  uint8_t* dimg = base + dst_off;
+  {
+    const int c4 = threadIdx.x & 63;                      // one wave stages one source row at a time
+    if (c4 < ncol4) {
+      const uint32_t* col = reinterpret_cast<const uint32_t*>(simg) + c4;
+      const int stride4 = src_stride >> 2;
+      for (int r = threadIdx.x >> 6; r < nrow; r += 4)
+        tile32[r * (PD_SW / 4) + c4] = col[mad24((uint32_t)min(sy0 + r, sh - 1), (uint32_t)stride4, 0u)];
+    }
   }
-  *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(base) + dst_off + (int64_t)y * dst_stride + x) = out;
+  __syncthreads();
+  const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;     // 32 quads across, 8 row pairs down
+  const int x = x0 + qx * 4;
+  if (x >= dw) return;
+  int o[4]; uint32_t c1[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int xi = min(x + i, dw - 1);
+    o[i] = xofs[xi] - sx0; c1[i] = (uint32_t)xc1[xi];
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; rr++) {
+    const int y = y0 + qy * 2 + rr;
+    if (y >= dh) break;
+    const uint8_t* r0 = tile + (yofs[y] - sy0) * PD_SW;
+    const uint8_t* r1 = r0 + PD_SW;
+    const uint32_t m1 = (uint32_t)yc1[y], m0 = 256u - m1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t c0 = 256u - c1[i];
+      // all factors are < 2^17 and every product < 2^32: 24-bit multiplies are exact here
+      const uint32_t h0 = mad24(c0, r0[o[i]], mad24(c1[i], r0[o[i] + 1], 0u));
+      const uint32_t h1 = mad24(c0, r1[o[i]], mad24(c1[i], r1[o[i] + 1], 0u));
+      out |= (mad24(h0, m0, mad24(h1, m1, 32768u)) >> 16) << (8 * i);
+    }
+    reinterpret_cast<uint32_t*>(dimg)[mad24((uint32_t)y, (uint32_t)(dst_stride >> 2), (uint32_t)(x >> 2))] = out;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -72,24 +127,68 @@ struct FastArgs {
   int* cand_count;
 };
 
-#define FT_W 64
-#define FT_H 32
-#define FT_LW (FT_W + 8)   // 72 bytes per staged row
-#define FT_LH (FT_H + 8)   // 40 rows
-#define FS_W (FT_W + 2)    // score plane 66 x 34
-#define FS_H (FT_H + 2)
+#define FT_W 128                 // output tile width (pixels)
+#define FT_H 32                  // output tile height
+#define FR_DW ((FT_W + 16) / 4)  // staged raw row: x0-8 .. x0+135, 36 dwords
+#define FR_H (FT_H + 8)          // staged raw rows: y0-4 .. y0+35
+#define FS_DW ((FT_W + 8) / 4)   // score row: x0-4 .. x0+131, 34 quads (dwords of 4 byte scores)
+#define FS_H (FT_H + 2)          // score rows: y0-1 .. y0+32
 
-__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }
-__device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }
+__device__ __forceinline__ int min3i(int a, int b, int c) {
+  int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ int max3i(int a, int b, int c) {
+  int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+// byte B (relative to the quad's own dword M; -4..-1 = left neighbour dword, 4..7 = right neighbour dword)
+template <int B>
+__device__ __forceinline__ int rbyte(uint32_t L, uint32_t M, uint32_t R) {
+  if constexpr (B < 0) return (int)((L >> (8 * (4 + B))) & 0xFFu);
+  else if constexpr (B < 4) return (int)((M >> (8 * B)) & 0xFFu);
+  else return (int)((R >> (8 * (B - 4))) & 0xFFu);
+}
+// corner score of pixel J (0..3) of a quad; L/M/R[0..6] = the three dwords of rows y-3 .. y+3. Branch-free.
+template <int J>
+__device__ __forceinline__ int fast_score_px(const uint32_t (&L)[7], const uint32_t (&M)[7], const uint32_t (&R)[7]) {
+  const int v = rbyte<J>(L[3], M[3], R[3]);
+  int d[16];
+  d[0] = v - rbyte<J>(L[6], M[6], R[6]);       d[1] = v - rbyte<J + 1>(L[6], M[6], R[6]);
+  d[2] = v - rbyte<J + 2>(L[5], M[5], R[5]);   d[3] = v - rbyte<J + 3>(L[4], M[4], R[4]);
+  d[4] = v - rbyte<J + 3>(L[3], M[3], R[3]);   d[5] = v - rbyte<J + 3>(L[2], M[2], R[2]);
+  d[6] = v - rbyte<J + 2>(L[1], M[1], R[1]);   d[7] = v - rbyte<J + 1>(L[0], M[0], R[0]);
+  d[8] = v - rbyte<J>(L[0], M[0], R[0]);       d[9] = v - rbyte<J - 1>(L[0], M[0], R[0]);
+  d[10] = v - rbyte<J - 2>(L[1], M[1], R[1]);  d[11] = v - rbyte<J - 3>(L[2], M[2], R[2]);
+  d[12] = v - rbyte<J - 3>(L[3], M[3], R[3]);  d[13] = v - rbyte<J - 3>(L[4], M[4], R[4]);
+  d[14] = v - rbyte<J - 2>(L[5], M[5], R[5]);  d[15] = v - rbyte<J - 1>(L[6], M[6], R[6]);
+  int lo3[16], hi3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+  }
+  int mn[16], mx[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn[k] = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);   // min of d over the arc k..k+8
+    mx[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);   // max of d over the arc k..k+8
+  }
+  int a = max3i(max3i(mn[0], mn[1], mn[2]), max3i(mn[3], mn[4], mn[5]), max3i(mn[6], mn[7], mn[8]));
+  a = max3i(a, max3i(mn[9], mn[10], mn[11]), max3i(mn[12], mn[13], mn[14]));
+  a = max(a, mn[15]);                                               // darker arcs: S+ = max_k min(d)
+  int b = min3i(min3i(mx[0], mx[1], mx[2]), min3i(mx[3], mx[4], mx[5]), min3i(mx[6], mx[7], mx[8]));
+  b = min3i(b, min3i(mx[9], mx[10], mx[11]), min3i(mx[12], mx[13], mx[14]));
+  b = min(b, mx[15]);                                               // brighter arcs: S- = -min_k max(d)
+  const int best = max(a, -b);
+  return best > EVH_FAST_THR ? best - 1 : 0;
+}
 
 __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
-  __shared__ uint32_t tile32[FT_LW * FT_LH / 4];
-  __shared__ uint8_t score[FS_W * FS_H + 2];
+  __shared__ uint32_t raw[FR_H * FR_DW];     // 40 x 36 dwords
+  __shared__ uint32_t score[FS_H * FS_DW];   // 34 x 34 quads of byte scores
   __shared__ uint32_t lst[FT_W * FT_H / 4];  // NMS keeps at most one corner per 2x2 block
   __shared__ int lcnt, gbase;
-  uint8_t* tile = reinterpret_cast<uint8_t*>(tile32);
   if (threadIdx.x == 0) lcnt = 0;
-  int f = blockIdx.y;
+  const int f = blockIdx.y;
   int t = blockIdx.x;
   int l = 0;
 #pragma unroll
@@ -97,79 +196,71 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
     if (t >= A.lv[i].tile_start) l = i;
   const EvhLevel L = A.lv[l];
   t -= L.tile_start;
-  int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-  int x0 = tx * FT_W, y0 = ty * FT_H;  // tile origin in level coordinates
+  const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+  const int x0 = tx * FT_W, y0 = ty * FT_H;  // tile origin in level coordinates
   const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-  // stage rows y0-4 .. y0+35, columns x0-4 .. x0+67 (clamped; clamped pixels never influence a tested centre)
-  for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += 256) {
-    int r = i / (FT_LW / 4), c4 = i - r * (FT_LW / 4);
-    int y = min(max(y0 - 4 + r, 0), L.h - 1);
-    int x = x0 - 4 + c4 * 4;
-    uint32_t v;
-    if (x >= 0 && x + 3 < L.stride) v = *reinterpret_cast<const uint32_t*>(img + (int64_t)y * L.stride + x);
-    else {
-      v = 0;
-      for (int k = 0; k < 4; k++) v |= (uint32_t)img[(int64_t)y * L.stride + min(max(x + k, 0), L.w - 1)] << (8 * k);
-    }
-    tile32[i] = v;
+  // ---- stage rows y0-4 .. y0+35, columns x0-8 .. x0+135 (out-of-image dwords read as 0: they only ever feed
+  //      pixels whose centre is outside the testable range, and those scores are forced to 0 below)
+  for (int i = threadIdx.x; i < FR_H * FR_DW; i += 256) {
+    const int r = i / FR_DW, c4 = i - r * FR_DW;
+    const int y = y0 - 4 + r, x = x0 - 8 + c4 * 4;
+    uint32_t v = 0;
+    if (y >= 0 && y < L.h && x >= 0 && x < L.stride) v = *reinterpret_cast<const uint32_t*>(img + (int64_t)y * L.stride + x);
+    raw[i] = v;
   }
   __syncthreads();
-  const int thr = EVH_FAST_THR;
-  for (int i = threadIdx.x; i < FS_W * FS_H; i += 256) {
-    int sy = i / FS_W, sx = i - sy * FS_W;
-    int x = x0 - 1 + sx, y = y0 - 1 + sy;
-    int s = 0;
-    if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
-      const uint8_t* p = tile + (sy + 3) * FT_LW + (sx + 3);
-      int v = p[0];
-      int d[16];
-      d[0] = v - p[3 * FT_LW];           d[1] = v - p[3 * FT_LW + 1];   d[2] = v - p[2 * FT_LW + 2];
-      d[3] = v - p[FT_LW + 3];           d[4] = v - p[3];               d[5] = v - p[-FT_LW + 3];
-      d[6] = v - p[-2 * FT_LW + 2];      d[7] = v - p[-3 * FT_LW + 1];  d[8] = v - p[-3 * FT_LW];
-      d[9] = v - p[-3 * FT_LW - 1];      d[10] = v - p[-2 * FT_LW - 2]; d[11] = v - p[-FT_LW - 3];
-      d[12] = v - p[-3];                 d[13] = v - p[FT_LW - 3];      d[14] = v - p[2 * FT_LW - 2];
-      d[15] = v - p[3 * FT_LW - 1];
-      // quick reject: any 9-arc holds two adjacent compass points (0,4,8,12)
-      bool dk = (d[0] > thr && d[4] > thr) || (d[4] > thr && d[8] > thr) || (d[8] > thr && d[12] > thr) ||
-                (d[12] > thr && d[0] > thr);
-      bool br = (d[0] < -thr && d[4] < -thr) || (d[4] < -thr && d[8] < -thr) || (d[8] < -thr && d[12] < -thr) ||
-                (d[12] < -thr && d[0] < -thr);
-      if (dk || br) {
-        int lo3[16], hi3[16];
+  // ---- corner scores of rows y0-1 .. y0+32, quads x0-4 .. x0+131; one thread = 4 adjacent pixels
+  for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
+    const int sr = i / FS_DW, sq = i - sr * FS_DW;
+    const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
+    uint32_t out = 0;
+    if (y >= 3 && y < L.h - 3 && xq + 3 >= 3 && xq < L.w - 3) {      // wave-divergent only at image borders
+      uint32_t Lr[7], Mr[7], Rr[7];
+      const uint32_t* p = raw + sr * FR_DW + sq;                      // row (y-3), dword of x = xq-4
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-          lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-          hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        }
-        int best = -256;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          int mn = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);    // min of d over arc k..k+8
-          int mx = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);    // max of d over arc k..k+8
-          best = max3i(best, mn, -mx);
-        }
-        if (best > thr) s = best - 1;
-      }
+      for (int r = 0; r < 7; r++) { Lr[r] = p[r * FR_DW]; Mr[r] = p[r * FR_DW + 1]; Rr[r] = p[r * FR_DW + 2]; }
+      int s0 = fast_score_px<0>(Lr, Mr, Rr), s1 = fast_score_px<1>(Lr, Mr, Rr);
+      int s2 = fast_score_px<2>(Lr, Mr, Rr), s3 = fast_score_px<3>(Lr, Mr, Rr);
+      if (xq < 3 || xq >= L.w - 3) s0 = 0;
+      if (xq + 1 < 3 || xq + 1 >= L.w - 3) s1 = 0;
+      if (xq + 2 < 3 || xq + 2 >= L.w - 3) s2 = 0;
+      if (xq + 3 < 3 || xq + 3 >= L.w - 3) s3 = 0;
+      out = (uint32_t)s0 | ((uint32_t)s1 << 8) | ((uint32_t)s2 << 16) | ((uint32_t)s3 << 24);
     }
-    score[i] = (uint8_t)s;
+    score[i] = out;
   }
   __syncthreads();
+  // ---- 3x3 non-max suppression + 31-px border filter; survivors go to an LDS list, ONE global atomic per
+  //      workgroup reserves their slots
   const bool level_ok = (L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE);
-  // NMS + border filter; survivors are collected in LDS, then ONE global atomic per workgroup reserves their slots
-  // (a returning global atomic per wave-iteration serialises on its ~1-2 us latency).
+  if (level_ok) {
 #pragma unroll 1
-  for (int k = 0; k < FT_W * FT_H / 256; k++) {
-    int i = threadIdx.x + k * 256;
-    int py = i / FT_W, px = i - py * FT_W;
-    int x = x0 + px, y = y0 + py;
-    const uint8_t* c = score + (py + 1) * FS_W + (px + 1);
-    int s = c[0];
-    if (s && level_ok && x >= EVH_EDGE && x < L.w - EVH_EDGE && y >= EVH_EDGE && y < L.h - EVH_EDGE) {
-      bool keep = s > c[-1] && s > c[1] && s > c[-FS_W - 1] && s > c[-FS_W] && s > c[-FS_W + 1] && s > c[FS_W - 1] &&
-                  s > c[FS_W] && s > c[FS_W + 1];
-      if (keep) {
-        int slot = atomicAdd(&lcnt, 1);
-        lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+    for (int k = 0; k < (FT_W / 4) * FT_H / 256; k++) {
+      const int i = threadIdx.x + k * 256;
+      const int qr = i / (FT_W / 4), qc = i - qr * (FT_W / 4);
+      const int y = y0 + qr, xq = x0 + qc * 4;
+      const uint32_t* p = score + (qr + 1) * FS_DW + (qc + 1);       // this quad, row y
+      const uint32_t m = p[0];
+      if (m == 0 || y < EVH_EDGE || y >= L.h - EVH_EDGE) continue;
+      const uint32_t lft = p[-1], rgt = p[1];
+      const uint32_t um = p[-FS_DW], ul = p[-FS_DW - 1], ur = p[-FS_DW + 1];
+      const uint32_t dm = p[FS_DW], dl = p[FS_DW - 1], dr = p[FS_DW + 1];
+      // 6-byte windows (x-1 .. x+4) of the three rows
+      const uint64_t wu = ((uint64_t)ur << 40) | ((uint64_t)um << 8) | (ul >> 24);
+      const uint64_t wm = ((uint64_t)rgt << 40) | ((uint64_t)m << 8) | (lft >> 24);
+      const uint64_t wd = ((uint64_t)dr << 40) | ((uint64_t)dm << 8) | (dl >> 24);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int s = (int)((wm >> (8 * (j + 1))) & 0xFF);
+        const int x = xq + j;
+        if (s == 0 || x < EVH_EDGE || x >= L.w - EVH_EDGE) continue;
+        const int n0 = (int)((wm >> (8 * j)) & 0xFF), n1 = (int)((wm >> (8 * (j + 2))) & 0xFF);
+        const int u0 = (int)((wu >> (8 * j)) & 0xFF), u1 = (int)((wu >> (8 * (j + 1))) & 0xFF), u2 = (int)((wu >> (8 * (j + 2))) & 0xFF);
+        const int d0 = (int)((wd >> (8 * j)) & 0xFF), d1 = (int)((wd >> (8 * (j + 1))) & 0xFF), d2 = (int)((wd >> (8 * (j + 2))) & 0xFF);
+        if (s > n0 && s > n1 && s > u0 && s > u1 && s > u2 && s > d0 && s > d1 && s > d2) {
+          const int slot = atomicAdd(&lcnt, 1);
+          lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        }
       }
     }
   }
@@ -495,8 +586,9 @@ int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int
   const EvhLevel& L = c->g.lv[0];
   int quads = ((L.w + 3) / 4) * L.h;
   dim3 grid((quads + 255) / 256, nframes);
+  const int aligned4 = (((uintptr_t)d_frames | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 3) == 0;
   hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, c->stream, d_frames, channels, row_stride, frame_stride, c->d_pyr,
-                     c->g.pyr_frame_bytes, L.w, L.h, L.stride);
+                     c->g.pyr_frame_bytes, L.w, L.h, L.stride, aligned4);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
@@ -505,11 +597,11 @@ int evh_launch_pyramid(evh_ctx* c, int nframes) {
   for (int l = 1; l < EVH_NLEVELS; l++) {
     const EvhLevel& S = c->g.lv[l - 1];
     const EvhLevel& D = c->g.lv[l];
-    int quads = ((D.w + 3) / 4) * D.h;
-    dim3 grid((quads + 255) / 256, nframes);
+    const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;
     const int* t = c->d_tabs + D.tab_off;
-    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, c->stream, c->d_pyr, c->g.pyr_frame_bytes, S.off, S.stride, D.off,
-                       D.stride, D.w, D.h, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
+    hipLaunchKernelGGL(k_pyr_down, dim3(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
+                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x, t, t + D.w,
+                       t + 2 * D.w, t + 2 * D.w + D.h);
     EVH_HIP(c, hipGetLastError());
   }
   return EVH_SUCCESS;

@@ -19,14 +19,18 @@
 namespace {
 
 #define WSYNC() __syncthreads()
-#define NL 64
+#define NL 64          // lanes of the wavefront
+#define NC 32          // hypotheses evaluated per chunk = lane-private matrix columns held in LDS
+// upper-triangle index of (i, j), i <= j, of an N x N symmetric matrix (the eigen-solver only touches i <= j)
+__device__ __forceinline__ int tri_index(int N, int i, int j) { return i * N - (i * (i - 1)) / 2 + (j - i); }
+#define TRI(N, i, j) tri_index((N), (i), (j))
 
 struct RansacLds {
-  double A[81 * NL];   // lane-private 9x9 (or 8x8) symmetric matrix, element-major: A[(i*N+j)*64 + lane]
-  double V[81 * NL];   // lane-private eigenvectors (rows)
-  double W[9 * NL];
-  int indR[9 * NL];
-  int indC[9 * NL];
+  double A[45 * NC];   // column-private symmetric 9x9 (or 8x8), upper triangle, element-major: A[TRI(i,j)*NC + col]
+  double V[81 * NC];   // column-private eigenvectors (rows), element-major
+  double W[9 * NC];
+  int indR[9 * NC];
+  int indC[9 * NC];
   double bestH[9];
   double H[9];         // result of the last single-problem DLT / LM
   double x[8], xd[8], v[8], d[8], D[8], tmpd[8], A8[64], Ap[64], Inv[64];
@@ -41,14 +45,14 @@ __device__ __forceinline__ double hyp(double a, double b) {
   return 0;
 }
 
-// Jacobi eigen-solver on the calling lane's LDS column. Eigenvalues descending in W, eigenvectors = rows of V.
+// Jacobi eigen-solver on LDS column `lane` (< NC). Eigenvalues descending in W, eigenvectors = rows of V.
 template <int N>
 __device__ void jacobi_lane(RansacLds& S, int lane) {
-#define A_(i, j) S.A[((i) * N + (j)) * NL + lane]
-#define V_(i, j) S.V[((i) * N + (j)) * NL + lane]
-#define W_(i) S.W[(i) * NL + lane]
-#define IR_(i) S.indR[(i) * NL + lane]
-#define IC_(i) S.indC[(i) * NL + lane]
+#define A_(i, j) S.A[TRI(N, i, j) * NC + lane]
+#define V_(i, j) S.V[((i) * N + (j)) * NC + lane]
+#define W_(i) S.W[(i) * NC + lane]
+#define IR_(i) S.indR[(i) * NC + lane]
+#define IC_(i) S.indC[(i) * NC + lane]
   const double eps = DBL_EPSILON;
   int i, j, k, m;
   for (i = 0; i < N; i++) { for (j = 0; j < N; j++) V_(i, j) = 0; V_(i, i) = 1; }
@@ -300,7 +304,7 @@ __device__ bool dlt_rows(RansacLds& S, int lane, const float* rows, int count, d
 #undef LXS
 #undef LYS
     }
-    S.A[(j * 9 + k) * NL + 0] = s;  // lane 0's matrix
+    S.A[TRI(9, j, k) * NC + 0] = s;  // column 0
   }
   WSYNC();
   if (lane == 0) {
@@ -318,26 +322,26 @@ __device__ void eig_solve8_lane0(RansacLds& S, const double* Ain /*LDS 64*/, con
                                  double* x /*LDS 8 or 64*/) {
   const int N = 8;
   for (int i = 0; i < 8; i++)
-    for (int j = 0; j < 8; j++) S.A[(i * N + j) * NL + 0] = Ain[i * 8 + j];
+    for (int j = i; j < 8; j++) S.A[TRI(8, i, j) * NC + 0] = Ain[i * 8 + j];
   jacobi_lane<8>(S, 0);
   double threshold = 0;
-  for (int i = 0; i < 8; i++) threshold += S.W[i * NL];
+  for (int i = 0; i < 8; i++) threshold += S.W[i * NC];
   threshold *= DBL_EPSILON * 2;
   const int nb = b ? 1 : 8;
   for (int i = 0; i < 8 * nb; i++) x[i] = 0;
   for (int i = 0; i < 8; i++) {
-    double wi = S.W[i * NL];
+    double wi = S.W[i * NC];
     if (fabs(wi) <= threshold) continue;
     wi = 1 / wi;
     if (b) {
       double s = 0;
-      for (int j = 0; j < 8; j++) s += S.V[(i * N + j) * NL] * b[j];
+      for (int j = 0; j < 8; j++) s += S.V[(i * N + j) * NC] * b[j];
       s *= wi;
-      for (int j = 0; j < 8; j++) x[j] = x[j] + s * S.V[(i * N + j) * NL];
+      for (int j = 0; j < 8; j++) x[j] = x[j] + s * S.V[(i * N + j) * NC];
     } else {
       for (int j = 0; j < 8; j++) {
-        double s = S.V[(i * N + j) * NL] * wi;
-        for (int r = 0; r < 8; r++) x[r * 8 + j] = x[r * 8 + j] + S.V[(i * N + r) * NL] * s;
+        double s = S.V[(i * N + j) * NC] * wi;
+        for (int r = 0; r < 8; r++) x[r * 8 + j] = x[r * 8 + j] + S.V[(i * N + r) * NC] * s;
       }
     }
   }
@@ -552,9 +556,9 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
   int niters = max(maxItersArg, 1), maxGood = 0, iter = 0, run = 0;
   bool stop = false, any_found = false;
   while (!stop && iter < niters) {
-    // every lane advances the generator identically through 64 quadruples and keeps quadruple #lane
-    int my[4] = {0, 0, 0, 0};
-    for (int h = 0; h < NL; h++) {
+    // every lane advances the generator identically through NC quadruples; lane h < NC keeps quadruple #h
+    int my[4] = {0, 1, 2, 3};
+    for (int h = 0; h < NC; h++) {
       int q[4];
       for (int i = 0; i < 4;) {
         int idx_i;
@@ -574,7 +578,7 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
       const float4 r = *reinterpret_cast<const float4*>(rows + 4 * my[i]);
       Mx[i] = r.x; My[i] = r.y; mx[i] = r.z; my_[i] = r.w;
     }
-    const bool valid = check_subset4(Mx, My, mx, my_);
+    const bool valid = lane < NC && check_subset4(Mx, My, mx, my_);
     double H[9];
     bool ok = false;
     int good = 0;
@@ -592,7 +596,7 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
     }
     const unsigned long long vmask = __ballot(valid), okmask = __ballot(ok);
     // sequential replay in sample order
-    for (int h = 0; h < NL; h++) {
+    for (int h = 0; h < NC; h++) {
       if (!((vmask >> h) & 1ull)) {  // rejected sample: counts towards the 10000-attempt bound of one draw
         if (++run >= 10000) { stop = true; break; }
         continue;
