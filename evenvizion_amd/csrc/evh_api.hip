@@ -73,6 +73,12 @@ void compute_geometry(int w, int h, int nfeatures, EvhGeom& g) {
     ndes *= factor;
   }
   g.lv[EVH_NLEVELS - 1].quota = std::max(nfeatures - sum, 0);
+  int kb = 0;
+  for (int l = 0; l < EVH_NLEVELS; l++) {   // room for ties at the Harris cut: quota + 25 % + 16 per level
+    g.lv[l].kp_base = kb;
+    g.lv[l].kp_cap = g.lv[l].quota + g.lv[l].quota / 4 + 16;
+    kb += g.lv[l].kp_cap;
+  }
 }
 
 // INTER_LINEAR_EXACT coefficient tables for one axis: offset of the left/top tap and the 8.8 weight of the
@@ -92,7 +98,7 @@ void linear_exact_tab(int ssize, int dsize, int* ofs, int* c1) {
   }
 }
 
-int kcap_for(int nfeatures) { return align_up(nfeatures + nfeatures / 4 + 64, 64); }
+int kcap_for(int nfeatures) { return align_up(nfeatures + nfeatures / 4 + 8 * 17 + 64, 64); }
 
 int configure(evh_ctx* c, int w, int h, int nfeatures) {
   if (c->geom_valid && c->g.w == w && c->g.h == h && c->g.nfeatures == nfeatures) return EVH_SUCCESS;
@@ -202,6 +208,9 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_desc, F * K * 32));
   A_(dalloc(c, &c->d_kp_count, F));
   A_(dalloc(c, &c->d_frame_flags, F));
+  A_(dalloc(c, &c->d_tmp_meta, F * K));
+  A_(dalloc(c, &c->d_tmp_resp, F * K));
+  A_(dalloc(c, &c->d_lvl_count, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_knn_idx, F * K * 2));
   A_(dalloc(c, &c->d_knn_d2, F * K * 2));
   A_(dalloc(c, &c->d_pts, F * K * 4));
@@ -228,7 +237,7 @@ void evh_destroy(evh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
-                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

@@ -149,43 +149,63 @@ __device__ __forceinline__ int rbyte(uint32_t L, uint32_t M, uint32_t R) {
 }
 // corner score of pixel J (0..3) of a quad; L/M/R[0..6] = the three dwords of rows y-3 .. y+3. Branch-free.
 template <int J>
-__device__ __forceinline__ int fast_score_px(const uint32_t (&L)[7], const uint32_t (&M)[7], const uint32_t (&R)[7]) {
+__device__ __forceinline__ void fast_diffs_px(const uint32_t (&L)[7], const uint32_t (&M)[7], const uint32_t (&R)[7],
+                                              short (&d)[16]) {
   const int v = rbyte<J>(L[3], M[3], R[3]);
-  int d[16];
-  d[0] = v - rbyte<J>(L[6], M[6], R[6]);       d[1] = v - rbyte<J + 1>(L[6], M[6], R[6]);
-  d[2] = v - rbyte<J + 2>(L[5], M[5], R[5]);   d[3] = v - rbyte<J + 3>(L[4], M[4], R[4]);
-  d[4] = v - rbyte<J + 3>(L[3], M[3], R[3]);   d[5] = v - rbyte<J + 3>(L[2], M[2], R[2]);
-  d[6] = v - rbyte<J + 2>(L[1], M[1], R[1]);   d[7] = v - rbyte<J + 1>(L[0], M[0], R[0]);
-  d[8] = v - rbyte<J>(L[0], M[0], R[0]);       d[9] = v - rbyte<J - 1>(L[0], M[0], R[0]);
-  d[10] = v - rbyte<J - 2>(L[1], M[1], R[1]);  d[11] = v - rbyte<J - 3>(L[2], M[2], R[2]);
-  d[12] = v - rbyte<J - 3>(L[3], M[3], R[3]);  d[13] = v - rbyte<J - 3>(L[4], M[4], R[4]);
-  d[14] = v - rbyte<J - 2>(L[5], M[5], R[5]);  d[15] = v - rbyte<J - 1>(L[6], M[6], R[6]);
-  int lo3[16], hi3[16];
+  d[0] = (short)(v - rbyte<J>(L[6], M[6], R[6]));       d[1] = (short)(v - rbyte<J + 1>(L[6], M[6], R[6]));
+  d[2] = (short)(v - rbyte<J + 2>(L[5], M[5], R[5]));   d[3] = (short)(v - rbyte<J + 3>(L[4], M[4], R[4]));
+  d[4] = (short)(v - rbyte<J + 3>(L[3], M[3], R[3]));   d[5] = (short)(v - rbyte<J + 3>(L[2], M[2], R[2]));
+  d[6] = (short)(v - rbyte<J + 2>(L[1], M[1], R[1]));   d[7] = (short)(v - rbyte<J + 1>(L[0], M[0], R[0]));
+  d[8] = (short)(v - rbyte<J>(L[0], M[0], R[0]));       d[9] = (short)(v - rbyte<J - 1>(L[0], M[0], R[0]));
+  d[10] = (short)(v - rbyte<J - 2>(L[1], M[1], R[1]));  d[11] = (short)(v - rbyte<J - 3>(L[2], M[2], R[2]));
+  d[12] = (short)(v - rbyte<J - 3>(L[3], M[3], R[3]));  d[13] = (short)(v - rbyte<J - 3>(L[4], M[4], R[4]));
+  d[14] = (short)(v - rbyte<J - 2>(L[5], M[5], R[5]));  d[15] = (short)(v - rbyte<J - 1>(L[6], M[6], R[6]));
+}
+
+// 16-bit VALU min/max issue at full rate on gfx950 (measured: 2 cycles per wave64 instruction), the 32-bit and
+// 3-input forms at half rate; the differences centre-ring fit int16, so the score trees run on the low halves.
+typedef short i16;
+__device__ __forceinline__ i16 mn16(i16 a, i16 b) { return a < b ? a : b; }
+__device__ __forceinline__ i16 mx16(i16 a, i16 b) { return a > b ? a : b; }
+__device__ __forceinline__ int sext16(i16 a) { return (int)a; }
+
+// Exact corner score from the 16 differences d[k] = centre - ring[k] (low 16 bits significant):
+// max over the 16 circular arcs of 9 of min(d) (darker) and of min(-d) (brighter).  Sliding minimum by block
+// prefix/suffix scans (blocks 0..7 and 8..15; arc k = 8b+r is suffix_b[r] joined with prefix_{b^1}[r]).
+__device__ __forceinline__ int fast_score_from_d(const i16 (&d)[16]) {
+  i16 Pn[2][8], Sn[2][8], Px[2][8], Sx[2][8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-  }
-  int mn[16], mx[16];
+  for (int b = 0; b < 2; b++) {
+    Pn[b][0] = d[8 * b]; Px[b][0] = d[8 * b];
+    Sn[b][7] = d[8 * b + 7]; Sx[b][7] = d[8 * b + 7];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn[k] = min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);   // min of d over the arc k..k+8
-    mx[k] = max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);   // max of d over the arc k..k+8
+    for (int r = 1; r < 8; r++) {
+      Pn[b][r] = mn16(Pn[b][r - 1], d[8 * b + r]);
+      Px[b][r] = mx16(Px[b][r - 1], d[8 * b + r]);
+      Sn[b][7 - r] = mn16(Sn[b][8 - r], d[8 * b + 7 - r]);
+      Sx[b][7 - r] = mx16(Sx[b][8 - r], d[8 * b + 7 - r]);
+    }
   }
-  int a = max3i(max3i(mn[0], mn[1], mn[2]), max3i(mn[3], mn[4], mn[5]), max3i(mn[6], mn[7], mn[8]));
-  a = max3i(a, max3i(mn[9], mn[10], mn[11]), max3i(mn[12], mn[13], mn[14]));
-  a = max(a, mn[15]);                                               // darker arcs: S+ = max_k min(d)
-  int b = min3i(min3i(mx[0], mx[1], mx[2]), min3i(mx[3], mx[4], mx[5]), min3i(mx[6], mx[7], mx[8]));
-  b = min3i(b, min3i(mx[9], mx[10], mx[11]), min3i(mx[12], mx[13], mx[14]));
-  b = min(b, mx[15]);                                               // brighter arcs: S- = -min_k max(d)
-  const int best = max(a, -b);
+  i16 a = mn16(Sn[0][0], Pn[1][0]);   // max over arcs of min(d)
+  i16 m = mx16(Sx[0][0], Px[1][0]);   // min over arcs of max(d)
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      if (b == 0 && r == 0) continue;
+      a = mx16(a, mn16(Sn[b][r], Pn[b ^ 1][r]));
+      m = mn16(m, mx16(Sx[b][r], Px[b ^ 1][r]));
+    }
+  const int best = max(sext16(a), -sext16(m));
   return best > EVH_FAST_THR ? best - 1 : 0;
 }
 
+#define FQ_PITCH (FS_DW * 4)   // score plane pitch in bytes (136)
+
 __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
-  __shared__ uint32_t raw[FR_H * FR_DW];     // 40 x 36 dwords
-  __shared__ uint32_t score[FS_H * FS_DW];   // 34 x 34 quads of byte scores
-  __shared__ uint32_t lst[FT_W * FT_H / 4];  // NMS keeps at most one corner per 2x2 block
+  __shared__ uint32_t raw[FR_H * FR_DW];      // 40 x 36 dwords: rows y0-4.., columns x0-8..
+  __shared__ uint32_t score[FS_H * FS_DW];    // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
+  __shared__ uint32_t lst[FT_W * FT_H / 4];   // NMS keeps at most one corner per 2x2 block
   __shared__ int lcnt, gbase;
   if (threadIdx.x == 0) lcnt = 0;
   const int f = blockIdx.y;
@@ -199,17 +219,25 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
   const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
   const int x0 = tx * FT_W, y0 = ty * FT_H;  // tile origin in level coordinates
   const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-  // ---- stage rows y0-4 .. y0+35, columns x0-8 .. x0+135 (out-of-image dwords read as 0: they only ever feed
-  //      pixels whose centre is outside the testable range, and those scores are forced to 0 below)
-  for (int i = threadIdx.x; i < FR_H * FR_DW; i += 256) {
-    const int r = i / FR_DW, c4 = i - r * FR_DW;
-    const int y = y0 - 4 + r, x = x0 - 8 + c4 * 4;
-    uint32_t v = 0;
-    if (y >= 0 && y < L.h && x >= 0 && x < L.stride) v = *reinterpret_cast<const uint32_t*>(img + (int64_t)y * L.stride + x);
-    raw[i] = v;
+  // ---- stage rows y0-4 .. y0+35, columns x0-8 .. x0+135 (dwords outside the image read as 0: they only feed
+  //      pixels whose centre is outside the testable range, which are never scored)
+  {
+    const int c4 = threadIdx.x & 63;
+    if (c4 < FR_DW) {
+      const int x = x0 - 8 + c4 * 4;
+      const bool xin = x >= 0 && x < L.stride;
+      const uint32_t* col = reinterpret_cast<const uint32_t*>(img) + (x >> 2);
+      const int stride4 = L.stride >> 2;
+      for (int r = threadIdx.x >> 6; r < FR_H; r += 4) {
+        const int y = y0 - 4 + r;
+        uint32_t v = 0;
+        if (xin && y >= 0 && y < L.h) v = col[mad24((uint32_t)y, (uint32_t)stride4, 0u)];
+        raw[r * FR_DW + c4] = v;
+      }
+    }
   }
   __syncthreads();
-  // ---- corner scores of rows y0-1 .. y0+32, quads x0-4 .. x0+131; one thread = 4 adjacent pixels
+  // ---- corner scores of rows y0-1 .. y0+32, quads x0-4 .. x0+131; one thread = 4 adjacent pixels, branch-free
   for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
     const int sr = i / FS_DW, sq = i - sr * FS_DW;
     const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
@@ -219,8 +247,11 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
       const uint32_t* p = raw + sr * FR_DW + sq;                      // row (y-3), dword of x = xq-4
 #pragma unroll
       for (int r = 0; r < 7; r++) { Lr[r] = p[r * FR_DW]; Mr[r] = p[r * FR_DW + 1]; Rr[r] = p[r * FR_DW + 2]; }
-      int s0 = fast_score_px<0>(Lr, Mr, Rr), s1 = fast_score_px<1>(Lr, Mr, Rr);
-      int s2 = fast_score_px<2>(Lr, Mr, Rr), s3 = fast_score_px<3>(Lr, Mr, Rr);
+      i16 d[16];
+      fast_diffs_px<0>(Lr, Mr, Rr, d); int s0 = fast_score_from_d(d);
+      fast_diffs_px<1>(Lr, Mr, Rr, d); int s1 = fast_score_from_d(d);
+      fast_diffs_px<2>(Lr, Mr, Rr, d); int s2 = fast_score_from_d(d);
+      fast_diffs_px<3>(Lr, Mr, Rr, d); int s3 = fast_score_from_d(d);
       if (xq < 3 || xq >= L.w - 3) s0 = 0;
       if (xq + 1 < 3 || xq + 1 >= L.w - 3) s1 = 0;
       if (xq + 2 < 3 || xq + 2 >= L.w - 3) s2 = 0;
@@ -284,6 +315,7 @@ struct SelectArgs {
   const uint32_t* cand; int64_t cand_frame_entries;
   const int* cand_count;
   float* kp_xy; uint32_t* kp_meta; float* kp_resp; int* kp_count; int* frame_flags;
+  uint32_t* tmp_meta; float* tmp_resp; int* lvl_count;   // per-level staging (segments at EvhLevel.kp_base)
   int kcap;
 };
 
@@ -315,24 +347,24 @@ __device__ __forceinline__ uint32_t f32_order_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// one workgroup per (level, frame): both retainBest stages + Harris + canonical order; results go to the level's
+// segment of the frame's staging arrays, k_pack then concatenates the eight segments.
 __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
   __shared__ uint32_t keys[EVH_K1CAP];
   __shared__ float resp[EVH_K1CAP];
   __shared__ uint32_t sel[EVH_K2CAP];
   __shared__ float selr[EVH_K2CAP];
   __shared__ uint32_t hist[256];
-  __shared__ int sh_i[8];  // 0: cut / prefix, 1: k1, 2: k2, 3: remaining, 4: overflow
-  const int f = blockIdx.x, tid = threadIdx.x;
-  int base = 0;
-  bool overflow = false;
-  for (int l = 0; l < EVH_NLEVELS; l++) {
-    const EvhLevel L = A.lv[l];
-    const uint32_t* cand = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
-    int n_raw = A.cand_count[f * EVH_NLEVELS + l];
-    if (n_raw > L.cand_cap) overflow = true;
-    const int n = min(n_raw, L.cand_cap);
-    const int q = L.quota;
-    if (n == 0 || q == 0) { __syncthreads(); continue; }
+  __shared__ int sh_i[8];  // 0: cut / digit, 1: k1, 2: k2, 3: remaining
+  const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const EvhLevel L = A.lv[l];
+  const uint32_t* cand = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
+  const int n_raw = A.cand_count[f * EVH_NLEVELS + l];
+  bool overflow = n_raw > L.cand_cap;
+  const int n = min(n_raw, L.cand_cap);
+  const int q = L.quota;
+  int k2 = 0;
+  if (n > 0 && q > 0) {
     // ---- stage 1: cut on the integer FAST score through a 256-bin histogram
     hist[tid] = 0;
     if (tid < 8) sh_i[tid] = 0;
@@ -401,28 +433,43 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
         if (slot < EVH_K2CAP) { sel[slot] = keys[j]; selr[slot] = resp[j]; }
       }
     __syncthreads();
-    int k2 = sh_i[2];
+    k2 = sh_i[2];
     if (k2 > EVH_K2CAP) { overflow = true; k2 = EVH_K2CAP; }
-    if (base + k2 > A.kcap) { overflow = true; k2 = max(A.kcap - base, 0); }
+    if (k2 > L.kp_cap) { overflow = true; k2 = L.kp_cap; }
     // ---- canonical order inside the level: ascending (y, x) by rank counting
     for (int j = tid; j < k2; j += 256) {
       uint32_t kj = sel[j] & 0xFFFFFFu;
       int pos = 0;
       for (int i = 0; i < k2; i++) pos += ((sel[i] & 0xFFFFFFu) < kj) ? 1 : 0;
-      int x = (int)(kj & 0xFFFu), y = (int)(kj >> 12);
-      int64_t o = (int64_t)f * A.kcap + base + pos;
-      A.kp_meta[o] = ((uint32_t)l << 24) | kj;
-      A.kp_xy[2 * o] = (float)x * L.scale;
-      A.kp_xy[2 * o + 1] = (float)y * L.scale;
-      A.kp_resp[o] = selr[j];
+      int64_t o = (int64_t)f * A.kcap + L.kp_base + pos;
+      A.tmp_meta[o] = ((uint32_t)l << 24) | kj;
+      A.tmp_resp[o] = selr[j];
     }
-    base += k2;
-    __syncthreads();
   }
   if (tid == 0) {
-    A.kp_count[f] = base;
-    A.frame_flags[f] = overflow ? 1 : 0;
+    A.lvl_count[f * EVH_NLEVELS + l] = k2;
+    if (overflow) atomicOr(&A.frame_flags[f], 1);
   }
+}
+
+// concatenates the per-level segments of one frame (canonical order = level, y, x) and derives kp.pt
+__global__ __launch_bounds__(256) void k_pack(SelectArgs A) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  int base = 0;
+  for (int l = 0; l < EVH_NLEVELS; l++) {
+    const EvhLevel L = A.lv[l];
+    const int n = A.lvl_count[f * EVH_NLEVELS + l];
+    for (int j = tid; j < n; j += 256) {
+      const int64_t si = (int64_t)f * A.kcap + L.kp_base + j, o = (int64_t)f * A.kcap + base + j;
+      const uint32_t m = A.tmp_meta[si];
+      A.kp_meta[o] = m;
+      A.kp_resp[o] = A.tmp_resp[si];
+      A.kp_xy[2 * o] = (float)(int)(m & 0xFFFu) * L.scale;          // keypoint.pt *= layerScale
+      A.kp_xy[2 * o + 1] = (float)(int)((m >> 12) & 0xFFFu) * L.scale;
+    }
+    base += n;
+  }
+  if (tid == 0) A.kp_count[f] = base;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -626,7 +673,11 @@ int evh_launch_select(evh_ctx* c, int nframes) {
   A.cand = c->d_cand; A.cand_frame_entries = c->g.cand_frame_entries; A.cand_count = c->d_cand_count;
   A.kp_xy = c->d_kp_xy; A.kp_meta = c->d_kp_meta; A.kp_resp = c->d_kp_resp; A.kp_count = c->d_kp_count;
   A.frame_flags = c->d_frame_flags; A.kcap = c->kcap;
-  hipLaunchKernelGGL(k_select, dim3(nframes), dim3(256), 0, c->stream, A);
+  A.tmp_meta = c->d_tmp_meta; A.tmp_resp = c->d_tmp_resp; A.lvl_count = c->d_lvl_count;
+  EVH_HIP(c, hipMemsetAsync(c->d_frame_flags, 0, sizeof(int) * (size_t)nframes, c->stream));
+  hipLaunchKernelGGL(k_select, dim3(EVH_NLEVELS, nframes), dim3(256), 0, c->stream, A);
+  EVH_HIP(c, hipGetLastError());
+  hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }

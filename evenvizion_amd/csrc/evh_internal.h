@@ -10,8 +10,8 @@
 #define EVH_NLEVELS 8
 #define EVH_EDGE 31          // ORB edgeThreshold
 #define EVH_FAST_THR 20      // ORB fastThreshold
-#define EVH_K1CAP 8192       // stage-1 (FAST-score) survivors per level held in LDS
-#define EVH_K2CAP 2048       // stage-2 (Harris) survivors per level held in LDS
+#define EVH_K1CAP 4096       // stage-1 (FAST-score) survivors per level held in LDS
+#define EVH_K2CAP 1280       // stage-2 (Harris) survivors per level held in LDS
 
 struct EvhLevel {
   int w, h, stride;     // stride in bytes (64-byte aligned)
@@ -23,6 +23,7 @@ struct EvhLevel {
   int tile_start;       // first FAST tile index of this level
   int tiles_x, tiles_y;
   int tab_off;          // offset (ints) of the resize tables of this level inside d_tabs
+  int kp_base, kp_cap;  // this level's segment inside a frame's keypoint staging arrays
 };
 
 struct EvhGeom {
@@ -54,6 +55,9 @@ struct evh_ctx {
   uint8_t* d_desc = nullptr;      // [max_frames][kcap][32]
   int* d_kp_count = nullptr;      // [max_frames]
   int* d_frame_flags = nullptr;   // [max_frames] bit0: capacity overflow
+  uint32_t* d_tmp_meta = nullptr; // [max_frames][kcap] per-level segments before packing
+  float* d_tmp_resp = nullptr;    // [max_frames][kcap]
+  int* d_lvl_count = nullptr;     // [max_frames][8]
   // pair buffers (max_pairs = max_frames)
   int32_t* d_knn_idx = nullptr;   // [max_pairs][kcap][2]
   uint32_t* d_knn_d2 = nullptr;   // [max_pairs][kcap][2]
