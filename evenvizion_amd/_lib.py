@@ -32,6 +32,7 @@ SIGNATURES = {
     "evh_profile_stage_name": (C.c_char_p, [_i]),
     "evh_resize_area_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp, _i, _i, _i64, _i64]),
     "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
+    "evh_set_fast_lift": (_i, [_vp, _i]),
     "evh_orb_count": (_i, [_vp, _i]),
     "evh_orb_capacity": (_i, [_vp]),
     "evh_orb_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -144,6 +145,9 @@ class Context:
         dh, dw = dst.shape[1:3]
         self._check(self.lib.evh_resize_area_u8(self.h, src.data_ptr(), n, sw, sh, cn, sw * cn, sw * sh * cn,
                                                 dst.data_ptr(), dw, dh, dw * cn, dw * dh * cn))
+
+    def set_fast_lift(self, on=True):
+        self._check(self.lib.evh_set_fast_lift(self.h, int(bool(on))))
 
     # ---- K1..K6 ----
     def orb_detect_batch(self, frames, nfeatures=500):

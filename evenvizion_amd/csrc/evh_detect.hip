@@ -125,6 +125,10 @@ struct FastArgs {
   uint8_t* pyr; int64_t pyr_frame_bytes;
   uint32_t* cand; int64_t cand_frame_entries;
   int* cand_count;
+  // threshold lifting (k_fast_lift): per (frame, level) score threshold, sampled score histogram, redo flags
+  int* thr;            // [F][8]
+  unsigned* shist;     // [F][8][256]
+  int* redo;           // [F][8]
 };
 
 #define FT_W 128                 // output tile width (pixels)
@@ -304,6 +308,200 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
   const int base = gbase;
   for (int i = threadIdx.x; i < n; i += 256)
     if (base + i < L.cand_cap) out[base + i] = lst[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3, threshold-lifted form.  ORB keeps only the 2*quota best-scoring FAST corners of a level (all ties at the
+// cut), typically <1 % of the corners found at threshold 20.  A corner with score >= T is kept by NMS and by that
+// selection exactly as before if every pixel with score < T is treated as "no corner": such neighbours cannot
+// suppress it and cannot be selected.  So the exact score is only needed for pixels that can reach T.
+//   SAMPLE: run threshold 20 on a 1/8 or 1/16 lattice of tiles, histogram the NMS-surviving scores;
+//   (k_fast_thr picks T per (frame, level) so that ~4x the needed 2*quota corners are expected above it)
+//   MAIN:   4-point pre-test at T (any 9-arc holds two adjacent compass points), queue survivors, exact score for
+//           the queue with all lanes busy, NMS, emit;
+//   (k_fast_verify: a level that ended with fewer than 2*quota corners although T > 20 is reset)
+//   REDO:   those levels again at threshold 20.  The result is identical to the dense kernel by construction.
+enum { FAST_SAMPLE = 0, FAST_MAIN = 1, FAST_REDO = 2 };
+
+__device__ __forceinline__ int fast_sample_mod(const EvhLevel& L) {
+  const int tiles = L.tiles_x * L.tiles_y;
+  return tiles >= 128 ? 16 : tiles >= 16 ? 8 : 0;   // 0: level too small to sample, threshold stays 20
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fast_lift(FastArgs A) {
+  __shared__ uint32_t raw[FR_H * FR_DW];        // 40 x 36 dwords: rows y0-4.., columns x0-8..
+  __shared__ uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
+  __shared__ uint32_t lst[FT_W * FT_H / 4];     // NMS keeps at most one corner per 2x2 block
+  __shared__ uint16_t queue[FS_H * FS_DW * 4];  // pixels that pass the pre-test (score-plane byte index)
+  __shared__ int lcnt, gbase, qcnt;
+  const int f = blockIdx.y;
+  int t = blockIdx.x;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < EVH_NLEVELS; i++)
+    if (t >= A.lv[i].tile_start) l = i;
+  const EvhLevel L = A.lv[l];
+  t -= L.tile_start;
+  const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+  int T = EVH_FAST_THR;
+  if (MODE == FAST_SAMPLE) {
+    const int mod = fast_sample_mod(L);
+    if (mod == 0 || ((tx + 3 * ty + f) % mod) != 0) return;
+  } else if (MODE == FAST_MAIN) {
+    T = A.thr[f * EVH_NLEVELS + l];
+  } else {
+    if (!A.redo[f * EVH_NLEVELS + l]) return;
+  }
+  if (threadIdx.x == 0) { lcnt = 0; qcnt = 0; }
+  const int x0 = tx * FT_W, y0 = ty * FT_H;  // tile origin in level coordinates
+  const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
+  {
+    const int c4 = threadIdx.x & 63;
+    if (c4 < FR_DW) {
+      const int x = x0 - 8 + c4 * 4;
+      const bool xin = x >= 0 && x < L.stride;
+      const uint32_t* col = reinterpret_cast<const uint32_t*>(img) + (x >> 2);
+      const int stride4 = L.stride >> 2;
+      for (int r = threadIdx.x >> 6; r < FR_H; r += 4) {
+        const int y = y0 - 4 + r;
+        uint32_t v = 0;
+        if (xin && y >= 0 && y < L.h) v = col[mad24((uint32_t)y, (uint32_t)stride4, 0u)];
+        raw[r * FR_DW + c4] = v;
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) score[i] = 0;
+  __syncthreads();
+  // ---- phase A: pre-test at T, one thread = 4 pixels
+  const i16 Tp = (i16)T, Tn = (i16)(-T);
+  for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
+    const int sr = i / FS_DW, sq = i - sr * FS_DW;
+    const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
+    if (y < 3 || y >= L.h - 3 || xq + 3 < 3 || xq >= L.w - 3) continue;
+    const uint32_t* p = raw + (sr + 3) * FR_DW + sq;          // centre row, dword of x = xq-4
+    const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
+    int npass = 0; int idx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int v = (int)((Mc >> (8 * j)) & 0xFF);
+      const i16 d0 = (i16)(v - (int)((Md >> (8 * j)) & 0xFF)), d8 = (i16)(v - (int)((Mu >> (8 * j)) & 0xFF));
+      const i16 d4 = (i16)(v - (j == 0 ? (int)(Mc >> 24) : (int)((Rc >> (8 * (j - 1))) & 0xFF)));
+      const i16 d12 = (i16)(v - (j == 3 ? (int)(Mc & 0xFF) : (int)((Lc >> (8 * (j + 1))) & 0xFF)));
+      const i16 lo = mx16(mx16(mn16(d0, d4), mn16(d4, d8)), mx16(mn16(d8, d12), mn16(d12, d0)));
+      const i16 hi = mn16(mn16(mx16(d0, d4), mx16(d4, d8)), mn16(mx16(d8, d12), mx16(d12, d0)));
+      const int x = xq + j;
+      const bool pass = (lo > Tp || hi < Tn) && x >= 3 && x < L.w - 3;
+      if (pass) idx[npass++] = sr * FQ_PITCH + sq * 4 + j;
+    }
+    if (npass) {
+      int slot = atomicAdd(&qcnt, npass);
+      for (int k = 0; k < npass; k++) queue[slot + k] = (uint16_t)idx[k];
+    }
+  }
+  __syncthreads();
+  // ---- phase B: exact score of the queued pixels; only scores >= T are recorded
+  {
+    const int nq = qcnt;
+    const uint8_t* rawb = reinterpret_cast<const uint8_t*>(raw);
+    uint8_t* scoreb = reinterpret_cast<uint8_t*>(score);
+    for (int i = threadIdx.x; i < nq; i += 256) {
+      const int pos = queue[i];
+      const int sr = pos / FQ_PITCH, sx = pos - sr * FQ_PITCH;
+      const uint8_t* p = rawb + (sr + 3) * (FR_DW * 4) + sx + 4;
+      const int W = FR_DW * 4;
+      const int v = p[0];
+      i16 d[16];
+      d[0] = (i16)(v - p[3 * W]);       d[1] = (i16)(v - p[3 * W + 1]);   d[2] = (i16)(v - p[2 * W + 2]);
+      d[3] = (i16)(v - p[W + 3]);       d[4] = (i16)(v - p[3]);           d[5] = (i16)(v - p[-W + 3]);
+      d[6] = (i16)(v - p[-2 * W + 2]);  d[7] = (i16)(v - p[-3 * W + 1]);  d[8] = (i16)(v - p[-3 * W]);
+      d[9] = (i16)(v - p[-3 * W - 1]);  d[10] = (i16)(v - p[-2 * W - 2]); d[11] = (i16)(v - p[-W - 3]);
+      d[12] = (i16)(v - p[-3]);         d[13] = (i16)(v - p[W - 3]);      d[14] = (i16)(v - p[2 * W - 2]);
+      d[15] = (i16)(v - p[3 * W - 1]);
+      const int s = fast_score_from_d(d);
+      if (s >= T) scoreb[pos] = (uint8_t)s;
+    }
+  }
+  __syncthreads();
+  // ---- 3x3 NMS + 31-px border filter
+  const bool level_ok = (L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE);
+  if (level_ok) {
+#pragma unroll 1
+    for (int k = 0; k < (FT_W / 4) * FT_H / 256; k++) {
+      const int i = threadIdx.x + k * 256;
+      const int qr = i / (FT_W / 4), qc = i - qr * (FT_W / 4);
+      const int y = y0 + qr, xq = x0 + qc * 4;
+      const uint32_t* p = score + (qr + 1) * FS_DW + (qc + 1);
+      const uint32_t m = p[0];
+      if (m == 0 || y < EVH_EDGE || y >= L.h - EVH_EDGE) continue;
+      const uint32_t lft = p[-1], rgt = p[1];
+      const uint32_t um = p[-FS_DW], ul = p[-FS_DW - 1], ur = p[-FS_DW + 1];
+      const uint32_t dm = p[FS_DW], dl = p[FS_DW - 1], dr = p[FS_DW + 1];
+      const uint64_t wu = ((uint64_t)ur << 40) | ((uint64_t)um << 8) | (ul >> 24);
+      const uint64_t wm = ((uint64_t)rgt << 40) | ((uint64_t)m << 8) | (lft >> 24);
+      const uint64_t wd = ((uint64_t)dr << 40) | ((uint64_t)dm << 8) | (dl >> 24);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int s = (int)((wm >> (8 * (j + 1))) & 0xFF);
+        const int x = xq + j;
+        if (s == 0 || x < EVH_EDGE || x >= L.w - EVH_EDGE) continue;
+        const int n0 = (int)((wm >> (8 * j)) & 0xFF), n1 = (int)((wm >> (8 * (j + 2))) & 0xFF);
+        const int u0 = (int)((wu >> (8 * j)) & 0xFF), u1 = (int)((wu >> (8 * (j + 1))) & 0xFF), u2 = (int)((wu >> (8 * (j + 2))) & 0xFF);
+        const int d0 = (int)((wd >> (8 * j)) & 0xFF), d1 = (int)((wd >> (8 * (j + 1))) & 0xFF), d2 = (int)((wd >> (8 * (j + 2))) & 0xFF);
+        if (s > n0 && s > n1 && s > u0 && s > u1 && s > u2 && s > d0 && s > d1 && s > d2) {
+          const int slot = atomicAdd(&lcnt, 1);
+          lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int n = lcnt;
+  if (n == 0) return;
+  if (MODE == FAST_SAMPLE) {
+    unsigned* h = A.shist + (int64_t)(f * EVH_NLEVELS + l) * 256;
+    for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&h[lst[i] >> 24], 1u);
+    return;
+  }
+  if (threadIdx.x == 0) gbase = atomicAdd(A.cand_count + f * EVH_NLEVELS + l, n);
+  __syncthreads();
+  uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
+  const int base = gbase;
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (base + i < L.cand_cap) out[base + i] = lst[i];
+}
+
+// per (frame, level): lifted threshold from the sampled histogram
+__global__ void k_fast_thr(FastArgs A, int nframes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nframes * EVH_NLEVELS) return;
+  const int l = i % EVH_NLEVELS;
+  const EvhLevel L = A.lv[l];
+  const int mod = fast_sample_mod(L);
+  int T = EVH_FAST_THR;
+  if (mod > 0 && L.quota > 0) {
+    const int need = max(24, (8 * L.quota + mod - 1) / mod);   // 4x the 2*quota corners the level must deliver
+    const unsigned* h = A.shist + (int64_t)i * 256;
+    int acc = 0;
+    for (int s = 255; s > EVH_FAST_THR; s--) {
+      acc += (int)h[s];
+      if (acc >= need) { T = s; break; }
+    }
+  }
+  A.thr[i] = T;
+  A.redo[i] = 0;
+}
+
+// per (frame, level): a lifted level that delivered fewer than 2*quota corners is redone at threshold 20
+__global__ void k_fast_verify(FastArgs A, int nframes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nframes * EVH_NLEVELS) return;
+  const int l = i % EVH_NLEVELS;
+  if (A.thr[i] > EVH_FAST_THR && A.cand_count[i] < 2 * A.lv[l].quota) {
+    A.cand_count[i] = 0;
+    A.thr[i] = EVH_FAST_THR;
+    A.redo[i] = 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -661,7 +859,20 @@ int evh_launch_fast(evh_ctx* c, int nframes) {
   A.pyr = c->d_pyr; A.pyr_frame_bytes = c->g.pyr_frame_bytes;
   A.cand = c->d_cand; A.cand_frame_entries = c->g.cand_frame_entries;
   A.cand_count = c->d_cand_count;
-  hipLaunchKernelGGL(k_fast, dim3(c->g.total_tiles, nframes), dim3(256), 0, c->stream, A);
+  A.thr = c->d_fast_thr; A.shist = c->d_fast_hist; A.redo = c->d_fast_redo;
+  const dim3 grid(c->g.total_tiles, nframes);
+  if (!c->fast_lift) {
+    hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, c->stream, A);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
+  const int nfl = nframes * EVH_NLEVELS;
+  EVH_HIP(c, hipMemsetAsync(c->d_fast_hist, 0, sizeof(unsigned) * 256 * (size_t)nfl, c->stream));
+  hipLaunchKernelGGL(k_fast_lift<FAST_SAMPLE>, grid, dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL(k_fast_thr, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
+  hipLaunchKernelGGL(k_fast_lift<FAST_MAIN>, grid, dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL(k_fast_verify, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
+  hipLaunchKernelGGL(k_fast_lift<FAST_REDO>, grid, dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }

@@ -58,6 +58,10 @@ struct evh_ctx {
   uint32_t* d_tmp_meta = nullptr; // [max_frames][kcap] per-level segments before packing
   float* d_tmp_resp = nullptr;    // [max_frames][kcap]
   int* d_lvl_count = nullptr;     // [max_frames][8]
+  int* d_fast_thr = nullptr;      // [max_frames][8] lifted FAST threshold
+  unsigned* d_fast_hist = nullptr;// [max_frames][8][256] sampled score histogram
+  int* d_fast_redo = nullptr;     // [max_frames][8]
+  bool fast_lift = true;
   // pair buffers (max_pairs = max_frames)
   int32_t* d_knn_idx = nullptr;   // [max_pairs][kcap][2]
   uint32_t* d_knn_d2 = nullptr;   // [max_pairs][kcap][2]

@@ -85,6 +85,11 @@ int evh_resize_area_u8(evh_ctx* ctx, const uint8_t* d_src, int nimg, int sw, int
  * (frame slots 0..nframes-1) until the next call.                                                              */
 int evh_orb_detect_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, int channels,
                          int64_t row_stride, int64_t frame_stride, int nfeatures);
+/* FAST threshold lifting (default on): the exact corner score is only evaluated for pixels that can reach the
+ * per-(frame, level) score that ORB's retainBest(2*quota) will cut at; keypoints and descriptors are identical
+ * either way (a level that comes up short is redone at threshold 20).  With lifting off the candidate lists
+ * returned by evh_orb_download_candidates hold every FAST corner at threshold 20.                          */
+int evh_set_fast_lift(evh_ctx* ctx, int on);
 /* number of keypoints of a frame slot, or <0 */
 int evh_orb_count(evh_ctx* ctx, int frame);
 /* capacity (rows) a caller must provide to evh_orb_download */

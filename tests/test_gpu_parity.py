@@ -63,7 +63,11 @@ def test_pyramid_and_gray(ctx, w, h):
 @pytest.mark.parametrize("w,h", SIZES)
 def test_fast_candidates(ctx, w, h):
     prev, cur, _ = S.make_pair(11, w, h)
-    ctx.orb_detect_batch(dev(np.stack([prev, cur])))
+    ctx.set_fast_lift(False)          # dense FAST: the candidate lists then hold every corner at threshold 20
+    try:
+        ctx.orb_detect_batch(dev(np.stack([prev, cur])))
+    finally:
+        ctx.set_fast_lift(True)
     pyr = O.orb_pyramid(cur)
     for l in range(8):
         gx, gy, gs = ctx.download_candidates(1, l)
@@ -89,6 +93,37 @@ def test_orb_keypoints_and_descriptors(ctx, w, h):
         assert np.array_equal(g["response"].view(np.uint32), o["response"].view(np.uint32))
         assert np.array_equal(g["angle"].view(np.uint32), o["angle"].view(np.uint32))
         assert np.array_equal(g["desc"], o["desc"])
+
+
+def test_fast_threshold_lifting_is_exact(ctx):
+    """Lifted FAST (default) == dense FAST == oracle, including the redo path: texture placed ONLY in the tiles the
+    sampling lattice looks at makes the sampled histogram over-estimate the level, the lifted pass comes up short
+    of 2*quota corners and the level must be redone at threshold 20."""
+    _, tex, _ = S.make_pair(17, 1280, 720)
+    frames = []
+    for f in range(2):
+        img = np.full((720, 1280), 120, np.uint8)
+        for ty in range(23):
+            for tx in range(10):
+                if (tx + 3 * ty + f) % 16 == 0:      # level-0 sampling lattice of k_fast_lift (128x32 tiles, mod 16)
+                    img[ty * 32:(ty + 1) * 32, tx * 128:(tx + 1) * 128] = tex[ty * 32:(ty + 1) * 32, tx * 128:(tx + 1) * 128]
+        frames.append(img)
+    frames.append(tex)
+    frames = np.stack(frames)
+    res = {}
+    for lift in (True, False):
+        ctx.set_fast_lift(lift)
+        ctx.orb_detect_batch(dev(frames))
+        res[lift] = [ctx.orb_download(f) for f in range(3)]
+    ctx.set_fast_lift(True)
+    for f in range(3):
+        o = O.orb_detect(frames[f])
+        assert len(o["xy"]) > 50
+        for lift in (True, False):
+            g = res[lift][f]
+            for k in ("octave", "lx", "ly"):
+                assert np.array_equal(g[k], o[k]), (lift, f, k)
+            assert np.array_equal(g["desc"], o["desc"]) and np.array_equal(g["xy"], o["xy"])
 
 
 def test_flat_frame_has_no_keypoints(ctx):
