@@ -59,19 +59,32 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { 
 #define PD_H 16
 #define PD_SW 168   // staged source row bytes (multiple of 4, >= 1.2*128 + 6)
 #define PD_SH 24    // staged source rows (>= 1.2*16 + 3)
+// INTER_LINEAR_EXACT sampling position of destination index v: left/top tap and the 8.8 weight of the right/bottom
+// tap (the same f64 operations, in the same order, as the host reference table in evh_api.hip; samples that fall
+// off either end put the full weight on the edge sample).
+__device__ __forceinline__ void lin_coef(int v, double scale, int ssize, int& ofs, uint32_t& c1) {
+  const double fval = scale * ((double)v + 0.5) - 0.5;
+  const int ival = (int)__builtin_floor(fval);
+  if (ival >= 0 && ssize > 1) {
+    if (ival < ssize - 1) { ofs = ival; c1 = (uint32_t)(int)__builtin_rint((fval - (double)ival) * 256.0); }
+    else { ofs = ssize - 2; c1 = 256u; }
+  } else { ofs = 0; c1 = 0u; }
+}
+
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t src_off,
                                                   int src_stride, int sw, int sh, int64_t dst_off, int dst_stride, int dw,
-                                                  int dh, int tiles_x, const int* __restrict__ xofs,
-                                                  const int* __restrict__ xc1, const int* __restrict__ yofs,
-                                                  const int* __restrict__ yc1) {
+                                                  int dh, int tiles_x, double scale_x, double scale_y) {
   __shared__ uint32_t tile32[PD_SH * PD_SW / 4];
   const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
   const int f = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int x0 = tx * PD_W, y0 = ty * PD_H;
   const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PD_H, dh) - 1;
-  const int sx0 = xofs[x0] & ~3, sy0 = yofs[y0];
-  const int ncol4 = (xofs[x1] + 1 - sx0) / 4 + 1, nrow = yofs[y1] + 2 - sy0;   // <= PD_SW/4, <= PD_SH
+  int ox0, ox1, oy0, oy1; uint32_t cdummy;
+  lin_coef(x0, scale_x, sw, ox0, cdummy); lin_coef(x1, scale_x, sw, ox1, cdummy);
+  lin_coef(y0, scale_y, sh, oy0, cdummy); lin_coef(y1, scale_y, sh, oy1, cdummy);
+  const int sx0 = ox0 & ~3, sy0 = oy0;
+  const int ncol4 = (ox1 + 1 - sx0) / 4 + 1, nrow = oy1 + 2 - sy0;   // <= PD_SW/4, <= PD_SH
   uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;   // wave-uniform 64-bit bases; per-lane offsets stay 32-bit
   const uint8_t* simg = base + src_off + sx0;
   uint8_t* dimg = base + dst_off;
@@ -84,28 +97,27 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
         tile32[r * (PD_SW / 4) + c4] = col[mad24((uint32_t)min(sy0 + r, sh - 1), (uint32_t)stride4, 0u)];
     }
   }
-  __syncthreads();
   const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;     // 32 quads across, 8 row pairs down
   const int x = x0 + qx * 4;
-  if (x >= dw) return;
   int o[4]; uint32_t c1[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int xi = min(x + i, dw - 1);
-    o[i] = xofs[xi] - sx0; c1[i] = (uint32_t)xc1[xi];
-  }
+  for (int i = 0; i < 4; i++) { lin_coef(min(x + i, dw - 1), scale_x, sw, o[i], c1[i]); o[i] -= sx0; }
+  int oy[2]; uint32_t m1v[2];
+#pragma unroll
+  for (int rr = 0; rr < 2; rr++) { lin_coef(min(y0 + qy * 2 + rr, dh - 1), scale_y, sh, oy[rr], m1v[rr]); oy[rr] -= sy0; }
+  __syncthreads();
+  if (x >= dw) return;
 #pragma unroll
   for (int rr = 0; rr < 2; rr++) {
     const int y = y0 + qy * 2 + rr;
     if (y >= dh) break;
-    const uint8_t* r0 = tile + (yofs[y] - sy0) * PD_SW;
+    const uint8_t* r0 = tile + oy[rr] * PD_SW;
     const uint8_t* r1 = r0 + PD_SW;
-    const uint32_t m1 = (uint32_t)yc1[y], m0 = 256u - m1;
+    const uint32_t m1 = m1v[rr], m0 = 256u - m1;
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint32_t c0 = 256u - c1[i];
-      // all factors are < 2^17 and every product < 2^32: 24-bit multiplies are exact here
       const uint32_t h0 = mad24(c0, r0[o[i]], mad24(c1[i], r0[o[i] + 1], 0u));
       const uint32_t h1 = mad24(c0, r1[o[i]], mad24(c1[i], r1[o[i] + 1], 0u));
       out |= (mad24(h0, m0, mad24(h1, m1, 32768u)) >> 16) << (8 * i);
@@ -129,6 +141,7 @@ struct FastArgs {
   int* thr;            // [F][8]
   unsigned* shist;     // [F][8][256]
   int* redo;           // [F][8]
+  int samp_start[EVH_NLEVELS], samp_mod[EVH_NLEVELS];   // sampling lattice of k_fast_sample
 };
 
 #define FT_W 128                 // output tile width (pixels)
@@ -206,49 +219,44 @@ __device__ __forceinline__ int fast_score_from_d(const i16 (&d)[16]) {
 
 #define FQ_PITCH (FS_DW * 4)   // score plane pitch in bytes (136)
 
-__global__ __launch_bounds__(256) void k_fast(FastArgs A) {
-  __shared__ uint32_t raw[FR_H * FR_DW];      // 40 x 36 dwords: rows y0-4.., columns x0-8..
-  __shared__ uint32_t score[FS_H * FS_DW];    // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
-  __shared__ uint32_t lst[FT_W * FT_H / 4];   // NMS keeps at most one corner per 2x2 block
-  __shared__ int lcnt, gbase;
-  if (threadIdx.x == 0) lcnt = 0;
-  const int f = blockIdx.y;
-  int t = blockIdx.x;
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < EVH_NLEVELS; i++)
-    if (t >= A.lv[i].tile_start) l = i;
-  const EvhLevel L = A.lv[l];
-  t -= L.tile_start;
-  const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-  const int x0 = tx * FT_W, y0 = ty * FT_H;  // tile origin in level coordinates
-  const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-  // ---- stage rows y0-4 .. y0+35, columns x0-8 .. x0+135 (dwords outside the image read as 0: they only feed
-  //      pixels whose centre is outside the testable range, which are never scored)
-  {
-    const int c4 = threadIdx.x & 63;
-    if (c4 < FR_DW) {
-      const int x = x0 - 8 + c4 * 4;
-      const bool xin = x >= 0 && x < L.stride;
-      const uint32_t* col = reinterpret_cast<const uint32_t*>(img) + (x >> 2);
-      const int stride4 = L.stride >> 2;
-      for (int r = threadIdx.x >> 6; r < FR_H; r += 4) {
-        const int y = y0 - 4 + r;
-        uint32_t v = 0;
-        if (xin && y >= 0 && y < L.h) v = col[mad24((uint32_t)y, (uint32_t)stride4, 0u)];
-        raw[r * FR_DW + c4] = v;
-      }
+
+struct FastLds {
+  uint32_t raw[FR_H * FR_DW];        // 40 x 36 dwords: rows y0-4.., columns x0-8..
+  uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
+  uint32_t lst[FT_W * FT_H / 4];     // NMS keeps at most one corner per 2x2 block
+  uint16_t queue[FS_H * FS_DW * 4];  // lifted path: pixels that pass the pre-test (score-plane byte index)
+  int lcnt, gbase, qcnt;
+};
+
+// stage rows y0-4 .. y0+35, columns x0-8 .. x0+135 (dwords outside the image read as 0: they only feed pixels
+// whose centre is outside the testable range, which are never scored); also clears the counters
+__device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const EvhLevel& L, int x0, int y0) {
+  if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; }
+  const int c4 = threadIdx.x & 63;
+  if (c4 < FR_DW) {
+    const int x = x0 - 8 + c4 * 4;
+    const bool xin = x >= 0 && x < L.stride;
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(img) + (x >> 2);
+    const int stride4 = L.stride >> 2;
+    for (int r = threadIdx.x >> 6; r < FR_H; r += 4) {
+      const int y = y0 - 4 + r;
+      uint32_t v = 0;
+      if (xin && y >= 0 && y < L.h) v = col[mad24((uint32_t)y, (uint32_t)stride4, 0u)];
+      S.raw[r * FR_DW + c4] = v;
     }
   }
-  __syncthreads();
-  // ---- corner scores of rows y0-1 .. y0+32, quads x0-4 .. x0+131; one thread = 4 adjacent pixels, branch-free
+}
+
+// dense path: exact scores (threshold 20) of rows y0-1 .. y0+32, quads x0-4 .. x0+131; one thread = 4 adjacent
+// pixels, ring bytes taken straight out of the row dwords (SDWA), branch-free
+__device__ __forceinline__ void fast_dense_scores(FastLds& S, const EvhLevel& L, int x0, int y0) {
   for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
     const int sr = i / FS_DW, sq = i - sr * FS_DW;
     const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
     uint32_t out = 0;
     if (y >= 3 && y < L.h - 3 && xq + 3 >= 3 && xq < L.w - 3) {      // wave-divergent only at image borders
       uint32_t Lr[7], Mr[7], Rr[7];
-      const uint32_t* p = raw + sr * FR_DW + sq;                      // row (y-3), dword of x = xq-4
+      const uint32_t* p = S.raw + sr * FR_DW + sq;                    // row (y-3), dword of x = xq-4
 #pragma unroll
       for (int r = 0; r < 7; r++) { Lr[r] = p[r * FR_DW]; Mr[r] = p[r * FR_DW + 1]; Rr[r] = p[r * FR_DW + 2]; }
       i16 d[16];
@@ -262,124 +270,20 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
       if (xq + 3 < 3 || xq + 3 >= L.w - 3) s3 = 0;
       out = (uint32_t)s0 | ((uint32_t)s1 << 8) | ((uint32_t)s2 << 16) | ((uint32_t)s3 << 24);
     }
-    score[i] = out;
+    S.score[i] = out;
   }
-  __syncthreads();
-  // ---- 3x3 non-max suppression + 31-px border filter; survivors go to an LDS list, ONE global atomic per
-  //      workgroup reserves their slots
-  const bool level_ok = (L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE);
-  if (level_ok) {
-#pragma unroll 1
-    for (int k = 0; k < (FT_W / 4) * FT_H / 256; k++) {
-      const int i = threadIdx.x + k * 256;
-      const int qr = i / (FT_W / 4), qc = i - qr * (FT_W / 4);
-      const int y = y0 + qr, xq = x0 + qc * 4;
-      const uint32_t* p = score + (qr + 1) * FS_DW + (qc + 1);       // this quad, row y
-      const uint32_t m = p[0];
-      if (m == 0 || y < EVH_EDGE || y >= L.h - EVH_EDGE) continue;
-      const uint32_t lft = p[-1], rgt = p[1];
-      const uint32_t um = p[-FS_DW], ul = p[-FS_DW - 1], ur = p[-FS_DW + 1];
-      const uint32_t dm = p[FS_DW], dl = p[FS_DW - 1], dr = p[FS_DW + 1];
-      // 6-byte windows (x-1 .. x+4) of the three rows
-      const uint64_t wu = ((uint64_t)ur << 40) | ((uint64_t)um << 8) | (ul >> 24);
-      const uint64_t wm = ((uint64_t)rgt << 40) | ((uint64_t)m << 8) | (lft >> 24);
-      const uint64_t wd = ((uint64_t)dr << 40) | ((uint64_t)dm << 8) | (dl >> 24);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int s = (int)((wm >> (8 * (j + 1))) & 0xFF);
-        const int x = xq + j;
-        if (s == 0 || x < EVH_EDGE || x >= L.w - EVH_EDGE) continue;
-        const int n0 = (int)((wm >> (8 * j)) & 0xFF), n1 = (int)((wm >> (8 * (j + 2))) & 0xFF);
-        const int u0 = (int)((wu >> (8 * j)) & 0xFF), u1 = (int)((wu >> (8 * (j + 1))) & 0xFF), u2 = (int)((wu >> (8 * (j + 2))) & 0xFF);
-        const int d0 = (int)((wd >> (8 * j)) & 0xFF), d1 = (int)((wd >> (8 * (j + 1))) & 0xFF), d2 = (int)((wd >> (8 * (j + 2))) & 0xFF);
-        if (s > n0 && s > n1 && s > u0 && s > u1 && s > u2 && s > d0 && s > d1 && s > d2) {
-          const int slot = atomicAdd(&lcnt, 1);
-          lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const int n = lcnt;
-  if (n == 0) return;
-  if (threadIdx.x == 0) gbase = atomicAdd(A.cand_count + f * EVH_NLEVELS + l, n);
-  __syncthreads();
-  uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
-  const int base = gbase;
-  for (int i = threadIdx.x; i < n; i += 256)
-    if (base + i < L.cand_cap) out[base + i] = lst[i];
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// K3, threshold-lifted form.  ORB keeps only the 2*quota best-scoring FAST corners of a level (all ties at the
-// cut), typically <1 % of the corners found at threshold 20.  A corner with score >= T is kept by NMS and by that
-// selection exactly as before if every pixel with score < T is treated as "no corner": such neighbours cannot
-// suppress it and cannot be selected.  So the exact score is only needed for pixels that can reach T.
-//   SAMPLE: run threshold 20 on a 1/8 or 1/16 lattice of tiles, histogram the NMS-surviving scores;
-//   (k_fast_thr picks T per (frame, level) so that ~4x the needed 2*quota corners are expected above it)
-//   MAIN:   4-point pre-test at T (any 9-arc holds two adjacent compass points), queue survivors, exact score for
-//           the queue with all lanes busy, NMS, emit;
-//   (k_fast_verify: a level that ended with fewer than 2*quota corners although T > 20 is reset)
-//   REDO:   those levels again at threshold 20.  The result is identical to the dense kernel by construction.
-enum { FAST_SAMPLE = 0, FAST_MAIN = 1, FAST_REDO = 2 };
-
-__device__ __forceinline__ int fast_sample_mod(const EvhLevel& L) {
-  const int tiles = L.tiles_x * L.tiles_y;
-  return tiles >= 128 ? 16 : tiles >= 16 ? 8 : 0;   // 0: level too small to sample, threshold stays 20
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_fast_lift(FastArgs A) {
-  __shared__ uint32_t raw[FR_H * FR_DW];        // 40 x 36 dwords: rows y0-4.., columns x0-8..
-  __shared__ uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
-  __shared__ uint32_t lst[FT_W * FT_H / 4];     // NMS keeps at most one corner per 2x2 block
-  __shared__ uint16_t queue[FS_H * FS_DW * 4];  // pixels that pass the pre-test (score-plane byte index)
-  __shared__ int lcnt, gbase, qcnt;
-  const int f = blockIdx.y;
-  int t = blockIdx.x;
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < EVH_NLEVELS; i++)
-    if (t >= A.lv[i].tile_start) l = i;
-  const EvhLevel L = A.lv[l];
-  t -= L.tile_start;
-  const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-  int T = EVH_FAST_THR;
-  if (MODE == FAST_SAMPLE) {
-    const int mod = fast_sample_mod(L);
-    if (mod == 0 || ((tx + 3 * ty + f) % mod) != 0) return;
-  } else if (MODE == FAST_MAIN) {
-    T = A.thr[f * EVH_NLEVELS + l];
-  } else {
-    if (!A.redo[f * EVH_NLEVELS + l]) return;
-  }
-  if (threadIdx.x == 0) { lcnt = 0; qcnt = 0; }
-  const int x0 = tx * FT_W, y0 = ty * FT_H;  // tile origin in level coordinates
-  const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-  {
-    const int c4 = threadIdx.x & 63;
-    if (c4 < FR_DW) {
-      const int x = x0 - 8 + c4 * 4;
-      const bool xin = x >= 0 && x < L.stride;
-      const uint32_t* col = reinterpret_cast<const uint32_t*>(img) + (x >> 2);
-      const int stride4 = L.stride >> 2;
-      for (int r = threadIdx.x >> 6; r < FR_H; r += 4) {
-        const int y = y0 - 4 + r;
-        uint32_t v = 0;
-        if (xin && y >= 0 && y < L.h) v = col[mad24((uint32_t)y, (uint32_t)stride4, 0u)];
-        raw[r * FR_DW + c4] = v;
-      }
-    }
-  }
-  for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) score[i] = 0;
-  __syncthreads();
-  // ---- phase A: pre-test at T, one thread = 4 pixels
+// lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
+// compass points) queues the pixels that can reach T; phase B: exact score of the queue with every lane busy.
+__device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, int x0, int y0, int T) {
+  for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) S.score[i] = 0;
   const i16 Tp = (i16)T, Tn = (i16)(-T);
   for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
     const int sr = i / FS_DW, sq = i - sr * FS_DW;
     const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
     if (y < 3 || y >= L.h - 3 || xq + 3 < 3 || xq >= L.w - 3) continue;
-    const uint32_t* p = raw + (sr + 3) * FR_DW + sq;          // centre row, dword of x = xq-4
+    const uint32_t* p = S.raw + (sr + 3) * FR_DW + sq;        // centre row, dword of x = xq-4
     const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
     int npass = 0; int idx[4];
 #pragma unroll
@@ -395,89 +299,150 @@ __global__ __launch_bounds__(256) void k_fast_lift(FastArgs A) {
       if (pass) idx[npass++] = sr * FQ_PITCH + sq * 4 + j;
     }
     if (npass) {
-      int slot = atomicAdd(&qcnt, npass);
-      for (int k = 0; k < npass; k++) queue[slot + k] = (uint16_t)idx[k];
+      int slot = atomicAdd(&S.qcnt, npass);
+      for (int k = 0; k < npass; k++) S.queue[slot + k] = (uint16_t)idx[k];
     }
   }
   __syncthreads();
-  // ---- phase B: exact score of the queued pixels; only scores >= T are recorded
-  {
-    const int nq = qcnt;
-    const uint8_t* rawb = reinterpret_cast<const uint8_t*>(raw);
-    uint8_t* scoreb = reinterpret_cast<uint8_t*>(score);
-    for (int i = threadIdx.x; i < nq; i += 256) {
-      const int pos = queue[i];
-      const int sr = pos / FQ_PITCH, sx = pos - sr * FQ_PITCH;
-      const uint8_t* p = rawb + (sr + 3) * (FR_DW * 4) + sx + 4;
-      const int W = FR_DW * 4;
-      const int v = p[0];
-      i16 d[16];
-      d[0] = (i16)(v - p[3 * W]);       d[1] = (i16)(v - p[3 * W + 1]);   d[2] = (i16)(v - p[2 * W + 2]);
-      d[3] = (i16)(v - p[W + 3]);       d[4] = (i16)(v - p[3]);           d[5] = (i16)(v - p[-W + 3]);
-      d[6] = (i16)(v - p[-2 * W + 2]);  d[7] = (i16)(v - p[-3 * W + 1]);  d[8] = (i16)(v - p[-3 * W]);
-      d[9] = (i16)(v - p[-3 * W - 1]);  d[10] = (i16)(v - p[-2 * W - 2]); d[11] = (i16)(v - p[-W - 3]);
-      d[12] = (i16)(v - p[-3]);         d[13] = (i16)(v - p[W - 3]);      d[14] = (i16)(v - p[2 * W - 2]);
-      d[15] = (i16)(v - p[3 * W - 1]);
-      const int s = fast_score_from_d(d);
-      if (s >= T) scoreb[pos] = (uint8_t)s;
-    }
+  const int nq = S.qcnt;
+  const uint8_t* rawb = reinterpret_cast<const uint8_t*>(S.raw);
+  uint8_t* scoreb = reinterpret_cast<uint8_t*>(S.score);
+  for (int i = threadIdx.x; i < nq; i += 256) {
+    const int pos = S.queue[i];
+    const int sr = pos / FQ_PITCH, sx = pos - sr * FQ_PITCH;
+    const uint8_t* p = rawb + (sr + 3) * (FR_DW * 4) + sx + 4;
+    const int W = FR_DW * 4;
+    const int v = p[0];
+    i16 d[16];
+    d[0] = (i16)(v - p[3 * W]);       d[1] = (i16)(v - p[3 * W + 1]);   d[2] = (i16)(v - p[2 * W + 2]);
+    d[3] = (i16)(v - p[W + 3]);       d[4] = (i16)(v - p[3]);           d[5] = (i16)(v - p[-W + 3]);
+    d[6] = (i16)(v - p[-2 * W + 2]);  d[7] = (i16)(v - p[-3 * W + 1]);  d[8] = (i16)(v - p[-3 * W]);
+    d[9] = (i16)(v - p[-3 * W - 1]);  d[10] = (i16)(v - p[-2 * W - 2]); d[11] = (i16)(v - p[-W - 3]);
+    d[12] = (i16)(v - p[-3]);         d[13] = (i16)(v - p[W - 3]);      d[14] = (i16)(v - p[2 * W - 2]);
+    d[15] = (i16)(v - p[3 * W - 1]);
+    const int s = fast_score_from_d(d);
+    if (s >= T) scoreb[pos] = (uint8_t)s;
   }
-  __syncthreads();
-  // ---- 3x3 NMS + 31-px border filter
-  const bool level_ok = (L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE);
-  if (level_ok) {
+}
+
+// 3x3 non-max suppression (strict '>' against all 8 neighbours) + 31-px border filter -> S.lst / S.lcnt
+__device__ __forceinline__ void fast_nms_collect(FastLds& S, const EvhLevel& L, int x0, int y0) {
+  if (!((L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE))) return;
 #pragma unroll 1
-    for (int k = 0; k < (FT_W / 4) * FT_H / 256; k++) {
-      const int i = threadIdx.x + k * 256;
-      const int qr = i / (FT_W / 4), qc = i - qr * (FT_W / 4);
-      const int y = y0 + qr, xq = x0 + qc * 4;
-      const uint32_t* p = score + (qr + 1) * FS_DW + (qc + 1);
-      const uint32_t m = p[0];
-      if (m == 0 || y < EVH_EDGE || y >= L.h - EVH_EDGE) continue;
-      const uint32_t lft = p[-1], rgt = p[1];
-      const uint32_t um = p[-FS_DW], ul = p[-FS_DW - 1], ur = p[-FS_DW + 1];
-      const uint32_t dm = p[FS_DW], dl = p[FS_DW - 1], dr = p[FS_DW + 1];
-      const uint64_t wu = ((uint64_t)ur << 40) | ((uint64_t)um << 8) | (ul >> 24);
-      const uint64_t wm = ((uint64_t)rgt << 40) | ((uint64_t)m << 8) | (lft >> 24);
-      const uint64_t wd = ((uint64_t)dr << 40) | ((uint64_t)dm << 8) | (dl >> 24);
+  for (int k = 0; k < (FT_W / 4) * FT_H / 256; k++) {
+    const int i = threadIdx.x + k * 256;
+    const int qr = i / (FT_W / 4), qc = i - qr * (FT_W / 4);
+    const int y = y0 + qr, xq = x0 + qc * 4;
+    const uint32_t* p = S.score + (qr + 1) * FS_DW + (qc + 1);       // this quad, row y
+    const uint32_t m = p[0];
+    if (m == 0 || y < EVH_EDGE || y >= L.h - EVH_EDGE) continue;
+    const uint32_t lft = p[-1], rgt = p[1];
+    const uint32_t um = p[-FS_DW], ul = p[-FS_DW - 1], ur = p[-FS_DW + 1];
+    const uint32_t dm = p[FS_DW], dl = p[FS_DW - 1], dr = p[FS_DW + 1];
+    // 6-byte windows (x-1 .. x+4) of the three rows
+    const uint64_t wu = ((uint64_t)ur << 40) | ((uint64_t)um << 8) | (ul >> 24);
+    const uint64_t wm = ((uint64_t)rgt << 40) | ((uint64_t)m << 8) | (lft >> 24);
+    const uint64_t wd = ((uint64_t)dr << 40) | ((uint64_t)dm << 8) | (dl >> 24);
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int s = (int)((wm >> (8 * (j + 1))) & 0xFF);
-        const int x = xq + j;
-        if (s == 0 || x < EVH_EDGE || x >= L.w - EVH_EDGE) continue;
-        const int n0 = (int)((wm >> (8 * j)) & 0xFF), n1 = (int)((wm >> (8 * (j + 2))) & 0xFF);
-        const int u0 = (int)((wu >> (8 * j)) & 0xFF), u1 = (int)((wu >> (8 * (j + 1))) & 0xFF), u2 = (int)((wu >> (8 * (j + 2))) & 0xFF);
-        const int d0 = (int)((wd >> (8 * j)) & 0xFF), d1 = (int)((wd >> (8 * (j + 1))) & 0xFF), d2 = (int)((wd >> (8 * (j + 2))) & 0xFF);
-        if (s > n0 && s > n1 && s > u0 && s > u1 && s > u2 && s > d0 && s > d1 && s > d2) {
-          const int slot = atomicAdd(&lcnt, 1);
-          lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
-        }
+    for (int j = 0; j < 4; j++) {
+      const int s = (int)((wm >> (8 * (j + 1))) & 0xFF);
+      const int x = xq + j;
+      if (s == 0 || x < EVH_EDGE || x >= L.w - EVH_EDGE) continue;
+      const int n0 = (int)((wm >> (8 * j)) & 0xFF), n1 = (int)((wm >> (8 * (j + 2))) & 0xFF);
+      const int u0 = (int)((wu >> (8 * j)) & 0xFF), u1 = (int)((wu >> (8 * (j + 1))) & 0xFF), u2 = (int)((wu >> (8 * (j + 2))) & 0xFF);
+      const int d0 = (int)((wd >> (8 * j)) & 0xFF), d1 = (int)((wd >> (8 * (j + 1))) & 0xFF), d2 = (int)((wd >> (8 * (j + 2))) & 0xFF);
+      if (s > n0 && s > n1 && s > u0 && s > u1 && s > u2 && s > d0 && s > d1 && s > d2) {
+        const int slot = atomicAdd(&S.lcnt, 1);
+        S.lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
       }
     }
   }
-  __syncthreads();
-  const int n = lcnt;
-  if (n == 0) return;
-  if (MODE == FAST_SAMPLE) {
-    unsigned* h = A.shist + (int64_t)(f * EVH_NLEVELS + l) * 256;
-    for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&h[lst[i] >> 24], 1u);
-    return;
-  }
-  if (threadIdx.x == 0) gbase = atomicAdd(A.cand_count + f * EVH_NLEVELS + l, n);
-  __syncthreads();
-  uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
-  const int base = gbase;
-  for (int i = threadIdx.x; i < n; i += 256)
-    if (base + i < L.cand_cap) out[base + i] = lst[i];
 }
 
-// per (frame, level): lifted threshold from the sampled histogram
+// survivors -> the level's candidate list; ONE global atomic per workgroup reserves the slots (a returning global
+// atomic per wave would serialise on its ~1-2 us latency)
+__device__ __forceinline__ void fast_emit(FastLds& S, const FastArgs& A, const EvhLevel& L, int f, int l) {
+  __syncthreads();
+  const int n = S.lcnt;
+  if (n > 0) {
+    if (threadIdx.x == 0) S.gbase = atomicAdd(A.cand_count + f * EVH_NLEVELS + l, n);
+    __syncthreads();
+    uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
+    const int base = S.gbase;
+    for (int i = threadIdx.x; i < n; i += 256)
+      if (base + i < L.cand_cap) out[base + i] = S.lst[i];
+  }
+}
+
+__device__ __forceinline__ int fast_level_of_tile(const FastArgs& A, int& t) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < EVH_NLEVELS; i++)
+    if (t >= A.lv[i].tile_start) l = i;
+  t -= A.lv[l].tile_start;
+  return l;
+}
+
+// K3 dense: every tile of every level at threshold 20
+__global__ __launch_bounds__(256) void k_fast(FastArgs A) {
+  __shared__ FastLds S;
+  const int f = blockIdx.y;
+  int t = blockIdx.x;
+  const int l = fast_level_of_tile(A, t);
+  const EvhLevel L = A.lv[l];
+  const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+  const int x0 = tx * FT_W, y0 = ty * FT_H;
+  fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
+  __syncthreads();
+  fast_dense_scores(S, L, x0, y0);
+  __syncthreads();
+  fast_nms_collect(S, L, x0, y0);
+  fast_emit(S, A, L, f, l);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3, threshold-lifted form.  ORB keeps only the 2*quota best-scoring FAST corners of a level (all ties at the
+// cut), typically <1 % of the corners found at threshold 20.  A corner with score >= T is kept by NMS and by that
+// selection exactly as before if every pixel with score < T is treated as "no corner": such neighbours cannot
+// suppress it and cannot be selected.  So the exact score is only needed for pixels that can reach T.
+//   k_fast_sample: threshold 20 on a sparse lattice of tiles (every 27th / 13th / 7th tile of a level), histogram
+//                  of the NMS-surviving scores;
+//   k_fast_thr:    T per (frame, level) such that ~4x the needed 2*quota corners are expected at or above it;
+//   k_fast_main:   all tiles at T (pre-test + queued exact scores; the dense path where T stayed 20);
+//   k_fast_verify: a lifted level that delivered fewer than 2*quota corners is reset ...
+//   k_fast_redo:   ... and redone at threshold 20.  The result equals the dense kernel's by construction.
+__global__ __launch_bounds__(256) void k_fast_sample(FastArgs A) {
+  __shared__ FastLds S;
+  const int f = blockIdx.y;
+  int s = blockIdx.x, l = 0;
+#pragma unroll
+  for (int i = 1; i < EVH_NLEVELS; i++)
+    if (s >= A.samp_start[i]) l = i;
+  s -= A.samp_start[l];
+  const int mod = A.samp_mod[l];
+  const EvhLevel L = A.lv[l];
+  if (mod == 0) return;
+  const int t = (f * 5 + l) % mod + s * mod;          // sampled tile index inside the level
+  if (t >= L.tiles_x * L.tiles_y) return;
+  const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+  const int x0 = tx * FT_W, y0 = ty * FT_H;
+  fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
+  __syncthreads();
+  fast_dense_scores(S, L, x0, y0);
+  __syncthreads();
+  fast_nms_collect(S, L, x0, y0);
+  __syncthreads();
+  const int n = S.lcnt;
+  unsigned* h = A.shist + (int64_t)(f * EVH_NLEVELS + l) * 256;
+  for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&h[S.lst[i] >> 24], 1u);
+}
+
 __global__ void k_fast_thr(FastArgs A, int nframes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nframes * EVH_NLEVELS) return;
   const int l = i % EVH_NLEVELS;
   const EvhLevel L = A.lv[l];
-  const int mod = fast_sample_mod(L);
+  const int mod = A.samp_mod[l];
   int T = EVH_FAST_THR;
   if (mod > 0 && L.quota > 0) {
     const int need = max(24, (8 * L.quota + mod - 1) / mod);   // 4x the 2*quota corners the level must deliver
@@ -492,7 +457,24 @@ __global__ void k_fast_thr(FastArgs A, int nframes) {
   A.redo[i] = 0;
 }
 
-// per (frame, level): a lifted level that delivered fewer than 2*quota corners is redone at threshold 20
+__global__ __launch_bounds__(256) void k_fast_main(FastArgs A) {
+  __shared__ FastLds S;
+  const int f = blockIdx.y;
+  int t = blockIdx.x;
+  const int l = fast_level_of_tile(A, t);
+  const EvhLevel L = A.lv[l];
+  const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+  const int x0 = tx * FT_W, y0 = ty * FT_H;
+  const int T = A.thr[f * EVH_NLEVELS + l];
+  fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
+  __syncthreads();
+  if (T > EVH_FAST_THR) fast_lift_scores(S, L, x0, y0, T);
+  else fast_dense_scores(S, L, x0, y0);
+  __syncthreads();
+  fast_nms_collect(S, L, x0, y0);
+  fast_emit(S, A, L, f, l);
+}
+
 __global__ void k_fast_verify(FastArgs A, int nframes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nframes * EVH_NLEVELS) return;
@@ -501,6 +483,26 @@ __global__ void k_fast_verify(FastArgs A, int nframes) {
     A.cand_count[i] = 0;
     A.thr[i] = EVH_FAST_THR;
     A.redo[i] = 1;
+  }
+}
+
+// one workgroup per (level, frame); does nothing unless the level was flagged, then walks all its tiles
+__global__ __launch_bounds__(256) void k_fast_redo(FastArgs A) {
+  __shared__ FastLds S;
+  const int l = blockIdx.x, f = blockIdx.y;
+  if (!A.redo[f * EVH_NLEVELS + l]) return;
+  const EvhLevel L = A.lv[l];
+  const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
+  for (int t = 0; t < L.tiles_x * L.tiles_y; t++) {
+    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    const int x0 = tx * FT_W, y0 = ty * FT_H;
+    __syncthreads();
+    fast_stage(S, img, L, x0, y0);
+    __syncthreads();
+    fast_dense_scores(S, L, x0, y0);
+    __syncthreads();
+    fast_nms_collect(S, L, x0, y0);
+    fast_emit(S, A, L, f, l);
   }
 }
 
@@ -843,10 +845,10 @@ int evh_launch_pyramid(evh_ctx* c, int nframes) {
     const EvhLevel& S = c->g.lv[l - 1];
     const EvhLevel& D = c->g.lv[l];
     const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;
-    const int* t = c->d_tabs + D.tab_off;
+    const double scale_x = 1.0 / ((double)D.w / S.w), scale_y = 1.0 / ((double)D.h / S.h);   // as cv::resize derives them
     hipLaunchKernelGGL(k_pyr_down, dim3(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
-                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x, t, t + D.w,
-                       t + 2 * D.w, t + 2 * D.w + D.h);
+                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x, scale_x,
+                       scale_y);
     EVH_HIP(c, hipGetLastError());
   }
   return EVH_SUCCESS;
@@ -860,19 +862,26 @@ int evh_launch_fast(evh_ctx* c, int nframes) {
   A.cand = c->d_cand; A.cand_frame_entries = c->g.cand_frame_entries;
   A.cand_count = c->d_cand_count;
   A.thr = c->d_fast_thr; A.shist = c->d_fast_hist; A.redo = c->d_fast_redo;
+  int nsamp = 0;
+  for (int l = 0; l < EVH_NLEVELS; l++) {
+    const int tiles = A.lv[l].tiles_x * A.lv[l].tiles_y;
+    A.samp_mod[l] = tiles >= 128 ? 27 : tiles >= 32 ? 13 : tiles >= 14 ? 7 : 0;   // 0: too small to sample, T stays 20
+    A.samp_start[l] = nsamp;
+    if (A.samp_mod[l]) nsamp += (tiles + A.samp_mod[l] - 1) / A.samp_mod[l];
+  }
   const dim3 grid(c->g.total_tiles, nframes);
-  if (!c->fast_lift) {
+  if (!c->fast_lift || nsamp == 0) {
     hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, c->stream, A);
     EVH_HIP(c, hipGetLastError());
     return EVH_SUCCESS;
   }
   const int nfl = nframes * EVH_NLEVELS;
   EVH_HIP(c, hipMemsetAsync(c->d_fast_hist, 0, sizeof(unsigned) * 256 * (size_t)nfl, c->stream));
-  hipLaunchKernelGGL(k_fast_lift<FAST_SAMPLE>, grid, dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL(k_fast_sample, dim3(nsamp, nframes), dim3(256), 0, c->stream, A);
   hipLaunchKernelGGL(k_fast_thr, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
-  hipLaunchKernelGGL(k_fast_lift<FAST_MAIN>, grid, dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL(k_fast_main, grid, dim3(256), 0, c->stream, A);
   hipLaunchKernelGGL(k_fast_verify, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
-  hipLaunchKernelGGL(k_fast_lift<FAST_REDO>, grid, dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL(k_fast_redo, dim3(EVH_NLEVELS, nframes), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
