@@ -55,7 +55,7 @@ void compute_geometry(int w, int h, int nfeatures, EvhGeom& g) {
     L.cand_cap = (L.w / 2 + 1) * (L.h / 2 + 1) + 64;  // NMS admits at most one corner per 2x2 block
     L.cand_off = coff;
     coff += L.cand_cap;
-    L.tiles_x = (L.w + 127) / 128; L.tiles_y = (L.h + 31) / 32;  // k_fast tile: 128 x 32
+    L.tiles_x = (L.w + 127) / 128; L.tiles_y = (L.h + 27) / 28;  // k_fast tile: 128 x 28
     L.tile_start = tiles;
     tiles += L.tiles_x * L.tiles_y;
     L.tab_off = tab;

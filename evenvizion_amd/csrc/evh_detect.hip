@@ -145,11 +145,11 @@ struct FastArgs {
 };
 
 #define FT_W 128                 // output tile width (pixels)
-#define FT_H 32                  // output tile height
+#define FT_H 28                  // output tile height (30 score rows x 34 quads = 1020 quads = 4 full passes of 256)
 #define FR_DW ((FT_W + 16) / 4)  // staged raw row: x0-8 .. x0+135, 36 dwords
-#define FR_H (FT_H + 8)          // staged raw rows: y0-4 .. y0+35
+#define FR_H (FT_H + 8)          // staged raw rows: y0-4 .. y0+FT_H+3
 #define FS_DW ((FT_W + 8) / 4)   // score row: x0-4 .. x0+131, 34 quads (dwords of 4 byte scores)
-#define FS_H (FT_H + 2)          // score rows: y0-1 .. y0+32
+#define FS_H (FT_H + 2)          // score rows: y0-1 .. y0+FT_H
 
 __device__ __forceinline__ int min3i(int a, int b, int c) {
   int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
@@ -225,25 +225,22 @@ struct FastLds {
   uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
   uint32_t lst[FT_W * FT_H / 4];     // NMS keeps at most one corner per 2x2 block
   uint16_t queue[FS_H * FS_DW * 4];  // lifted path: pixels that pass the pre-test (score-plane byte index)
-  int lcnt, gbase, qcnt;
+  uint16_t scored[FT_W * FT_H / 2];  // lifted path: pixels whose exact score reached T
+  int lcnt, gbase, qcnt, scnt;
 };
 
-// stage rows y0-4 .. y0+35, columns x0-8 .. x0+135 (dwords outside the image read as 0: they only feed pixels
-// whose centre is outside the testable range, which are never scored); also clears the counters
+// stage rows y0-4 .. y0+FT_H+3, columns x0-8 .. x0+135 with 8-byte loads (data outside the image reads as 0: it
+// only feeds pixels whose centre is outside the testable range, which are never scored); clears the counters
 __device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const EvhLevel& L, int x0, int y0) {
-  if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; }
-  const int c4 = threadIdx.x & 63;
-  if (c4 < FR_DW) {
-    const int x = x0 - 8 + c4 * 4;
-    const bool xin = x >= 0 && x < L.stride;
-    const uint32_t* col = reinterpret_cast<const uint32_t*>(img) + (x >> 2);
-    const int stride4 = L.stride >> 2;
-    for (int r = threadIdx.x >> 6; r < FR_H; r += 4) {
-      const int y = y0 - 4 + r;
-      uint32_t v = 0;
-      if (xin && y >= 0 && y < L.h) v = col[mad24((uint32_t)y, (uint32_t)stride4, 0u)];
-      S.raw[r * FR_DW + c4] = v;
-    }
+  if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; S.scnt = 0; }
+  const int stride8 = L.stride >> 3;
+  const uint2* img8 = reinterpret_cast<const uint2*>(img);
+  for (int i = threadIdx.x; i < FR_H * (FR_DW / 2); i += 256) {
+    const int r = i / (FR_DW / 2), c8 = i - r * (FR_DW / 2);
+    const int y = y0 - 4 + r, x = x0 - 8 + c8 * 8;
+    uint2 v = make_uint2(0u, 0u);
+    if (x >= 0 && x < L.stride && y >= 0 && y < L.h) v = img8[mad24((uint32_t)y, (uint32_t)stride8, (uint32_t)(x >> 3))];
+    *reinterpret_cast<uint2*>(&S.raw[r * FR_DW + c8 * 2]) = v;
   }
 }
 
@@ -274,34 +271,56 @@ __device__ __forceinline__ void fast_dense_scores(FastLds& S, const EvhLevel& L,
   }
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// {0, byte selB, 0, byte selA} of the 8-byte window {hi:lo} -> two zero-extended 16-bit lanes (one v_perm_b32)
+__device__ __forceinline__ s16x2 pk_bytes(uint32_t hi, uint32_t lo, uint32_t selA, uint32_t selB) {
+  uint32_t r = __builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (selB << 16) | selA);
+  return __builtin_bit_cast(s16x2, r);
+}
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+// sign bits (0x8000 per lane) set where the 4-point pre-test FAILS at threshold T for a pixel pair:
+// pass <=> two adjacent compass differences both > T, or both < -T
+__device__ __forceinline__ uint32_t pretest_fail2(s16x2 c, s16x2 rd, s16x2 rr, s16x2 ru, s16x2 rl, s16x2 Tp1, s16x2 nTm1) {
+  const s16x2 d0 = c - rd, d4 = c - rr, d8 = c - ru, d12 = c - rl;
+  const s16x2 lo = pmax(pmax(pmin(d0, d4), pmin(d4, d8)), pmax(pmin(d8, d12), pmin(d12, d0)));
+  const s16x2 hi = pmin(pmin(pmax(d0, d4), pmax(d4, d8)), pmin(pmax(d8, d12), pmax(d12, d0)));
+  const s16x2 t1 = lo - Tp1;      // >= 0  <=>  lo > T
+  const s16x2 t2 = nTm1 - hi;     // >= 0  <=>  hi < -T
+  return __builtin_bit_cast(uint32_t, t1) & __builtin_bit_cast(uint32_t, t2) & 0x80008000u;
+}
+
 // lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
-// compass points) queues the pixels that can reach T; phase B: exact score of the queue with every lane busy.
+// compass points), two pixels per packed 16-bit operation, queues the pixels that can reach T; phase B: exact
+// score of the queue with every lane busy.
 __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, int x0, int y0, int T) {
-  for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) S.score[i] = 0;
-  const i16 Tp = (i16)T, Tn = (i16)(-T);
+  const s16x2 Tp1 = {(short)(T + 1), (short)(T + 1)}, nTm1 = {(short)(-T - 1), (short)(-T - 1)};
+  // (sr, sq) walk the 34 x 34 quad grid without divisions: +256 quads = +7 rows +18 quads
+  int sr = threadIdx.x / FS_DW, sq = threadIdx.x - sr * FS_DW;
   for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
-    const int sr = i / FS_DW, sq = i - sr * FS_DW;
     const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
-    if (y < 3 || y >= L.h - 3 || xq + 3 < 3 || xq >= L.w - 3) continue;
-    const uint32_t* p = S.raw + (sr + 3) * FR_DW + sq;        // centre row, dword of x = xq-4
-    const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
-    int npass = 0; int idx[4];
+    S.score[i] = 0;                                             // phase B overwrites the bytes that reach T
+    if (y >= 3 && y < L.h - 3 && xq + 3 >= 3 && xq < L.w - 3) {
+      const uint32_t* p = S.raw + (sr + 3) * FR_DW + sq;        // centre row, dword of x = xq-4
+      const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
+      const uint32_t f01 = pretest_fail2(pk_bytes(Mc, Mc, 0, 1), pk_bytes(Md, Md, 0, 1), pk_bytes(Rc, Mc, 3, 4),
+                                         pk_bytes(Mu, Mu, 0, 1), pk_bytes(Mc, Lc, 1, 2), Tp1, nTm1);
+      const uint32_t f23 = pretest_fail2(pk_bytes(Mc, Mc, 2, 3), pk_bytes(Md, Md, 2, 3), pk_bytes(Rc, Mc, 5, 6),
+                                         pk_bytes(Mu, Mu, 2, 3), pk_bytes(Mc, Lc, 3, 4), Tp1, nTm1);
+      // bit j set <=> pixel j passes and lies in the testable column range
+      uint32_t pm = (((f01 >> 15) & 1u) | ((f01 >> 30) & 2u) | ((f23 >> 13) & 4u) | ((f23 >> 28) & 8u)) ^ 0xFu;
+      const int lo = max(3 - xq, 0), hi = min(L.w - 3 - xq, 4);   // valid pixels j in [lo, hi)
+      pm &= (0xFu << lo) & (0xFu >> (4 - hi));
+      if (pm) {
+        int slot = atomicAdd(&S.qcnt, __popc(pm));
+        const int basei = sr * FQ_PITCH + sq * 4;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int v = (int)((Mc >> (8 * j)) & 0xFF);
-      const i16 d0 = (i16)(v - (int)((Md >> (8 * j)) & 0xFF)), d8 = (i16)(v - (int)((Mu >> (8 * j)) & 0xFF));
-      const i16 d4 = (i16)(v - (j == 0 ? (int)(Mc >> 24) : (int)((Rc >> (8 * (j - 1))) & 0xFF)));
-      const i16 d12 = (i16)(v - (j == 3 ? (int)(Mc & 0xFF) : (int)((Lc >> (8 * (j + 1))) & 0xFF)));
-      const i16 lo = mx16(mx16(mn16(d0, d4), mn16(d4, d8)), mx16(mn16(d8, d12), mn16(d12, d0)));
-      const i16 hi = mn16(mn16(mx16(d0, d4), mx16(d4, d8)), mn16(mx16(d8, d12), mx16(d12, d0)));
-      const int x = xq + j;
-      const bool pass = (lo > Tp || hi < Tn) && x >= 3 && x < L.w - 3;
-      if (pass) idx[npass++] = sr * FQ_PITCH + sq * 4 + j;
+        for (int j = 0; j < 4; j++)
+          if (pm & (1u << j)) S.queue[slot++] = (uint16_t)(basei + j);
+      }
     }
-    if (npass) {
-      int slot = atomicAdd(&S.qcnt, npass);
-      for (int k = 0; k < npass; k++) S.queue[slot + k] = (uint16_t)idx[k];
-    }
+    sr += 7; sq += 18;
+    if (sq >= FS_DW) { sq -= FS_DW; sr++; }
   }
   __syncthreads();
   const int nq = S.qcnt;
@@ -309,8 +328,8 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
   uint8_t* scoreb = reinterpret_cast<uint8_t*>(S.score);
   for (int i = threadIdx.x; i < nq; i += 256) {
     const int pos = S.queue[i];
-    const int sr = pos / FQ_PITCH, sx = pos - sr * FQ_PITCH;
-    const uint8_t* p = rawb + (sr + 3) * (FR_DW * 4) + sx + 4;
+    const int sr2 = pos / FQ_PITCH, sx = pos - sr2 * FQ_PITCH;
+    const uint8_t* p = rawb + (sr2 + 3) * (FR_DW * 4) + sx + 4;
     const int W = FR_DW * 4;
     const int v = p[0];
     i16 d[16];
@@ -321,7 +340,32 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
     d[12] = (i16)(v - p[-3]);         d[13] = (i16)(v - p[W - 3]);      d[14] = (i16)(v - p[2 * W - 2]);
     d[15] = (i16)(v - p[3 * W - 1]);
     const int s = fast_score_from_d(d);
-    if (s >= T) scoreb[pos] = (uint8_t)s;
+    if (s >= T) {
+      scoreb[pos] = (uint8_t)s;
+      const int k = atomicAdd(&S.scnt, 1);
+      if (k < FT_W * FT_H / 2) S.scored[k] = (uint16_t)pos;
+    }
+  }
+}
+
+// lifted path NMS: only the (few) pixels that reached T are visited
+__device__ __forceinline__ void fast_nms_scored(FastLds& S, const EvhLevel& L, int x0, int y0) {
+  if (!((L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE))) return;
+  const uint8_t* sc = reinterpret_cast<const uint8_t*>(S.score);
+  const int n = min(S.scnt, FT_W * FT_H / 2);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int pos = S.scored[i];
+    const int sr = pos / FQ_PITCH, sx = pos - sr * FQ_PITCH;
+    if (sr < 1 || sr > FT_H || sx < 4 || sx >= 4 + FT_W) continue;     // halo pixels belong to neighbouring tiles
+    const int x = x0 - 4 + sx, y = y0 - 1 + sr;
+    if (x < EVH_EDGE || x >= L.w - EVH_EDGE || y < EVH_EDGE || y >= L.h - EVH_EDGE) continue;
+    const uint8_t* c = sc + pos;
+    const int s = c[0];
+    if (s > c[-1] && s > c[1] && s > c[-FQ_PITCH - 1] && s > c[-FQ_PITCH] && s > c[-FQ_PITCH + 1] &&
+        s > c[FQ_PITCH - 1] && s > c[FQ_PITCH] && s > c[FQ_PITCH + 1]) {
+      const int slot = atomicAdd(&S.lcnt, 1);
+      S.lst[slot] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+    }
   }
 }
 
@@ -329,8 +373,7 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
 __device__ __forceinline__ void fast_nms_collect(FastLds& S, const EvhLevel& L, int x0, int y0) {
   if (!((L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE))) return;
 #pragma unroll 1
-  for (int k = 0; k < (FT_W / 4) * FT_H / 256; k++) {
-    const int i = threadIdx.x + k * 256;
+  for (int i = threadIdx.x; i < (FT_W / 4) * FT_H; i += 256) {
     const int qr = i / (FT_W / 4), qc = i - qr * (FT_W / 4);
     const int y = y0 + qr, xq = x0 + qc * 4;
     const uint32_t* p = S.score + (qr + 1) * FS_DW + (qc + 1);       // this quad, row y
@@ -468,10 +511,16 @@ __global__ __launch_bounds__(256) void k_fast_main(FastArgs A) {
   const int T = A.thr[f * EVH_NLEVELS + l];
   fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
   __syncthreads();
-  if (T > EVH_FAST_THR) fast_lift_scores(S, L, x0, y0, T);
-  else fast_dense_scores(S, L, x0, y0);
-  __syncthreads();
-  fast_nms_collect(S, L, x0, y0);
+  if (T > EVH_FAST_THR) {
+    fast_lift_scores(S, L, x0, y0, T);
+    __syncthreads();
+    if (S.scnt <= FT_W * FT_H / 2) fast_nms_scored(S, L, x0, y0);
+    else fast_nms_collect(S, L, x0, y0);          // the short list overflowed: the score plane itself is complete
+  } else {
+    fast_dense_scores(S, L, x0, y0);
+    __syncthreads();
+    fast_nms_collect(S, L, x0, y0);
+  }
   fast_emit(S, A, L, f, l);
 }
 

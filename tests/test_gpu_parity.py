@@ -103,10 +103,10 @@ def test_fast_threshold_lifting_is_exact(ctx):
     frames = []
     for f in range(2):
         img = np.full((720, 1280), 120, np.uint8)
-        for t in range(230):                          # level 0 = 10 x 23 tiles of 128 x 32
+        for t in range(260):                          # level 0 = 10 x 26 tiles of 128 x 28
             if t % 27 == (f * 5) % 27:                # k_fast_sample's lattice for level 0 (every 27th tile)
                 ty, tx = divmod(t, 10)
-                img[ty * 32:(ty + 1) * 32, tx * 128:(tx + 1) * 128] = tex[ty * 32:(ty + 1) * 32, tx * 128:(tx + 1) * 128]
+                img[ty * 28:(ty + 1) * 28, tx * 128:(tx + 1) * 128] = tex[ty * 28:(ty + 1) * 28, tx * 128:(tx + 1) * 128]
         frames.append(img)
     frames.append(tex)
     frames = np.stack(frames)
