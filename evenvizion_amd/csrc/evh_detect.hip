@@ -55,6 +55,9 @@ __global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {   // a*b + c, a,b < 2^24 (half-rate VALU;
   uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;   // v_mul_lo_u32 / v_mad_u64_u32 are far slower)
 }
+__device__ __forceinline__ int mad24s(int a, int b, int c) {   // signed a*b + c, |a|,|b| < 2^23
+  int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
 #define PD_W 128
 #define PD_H 16
 #define PD_SW 168   // staged source row bytes (multiple of 4, >= 1.2*128 + 6)
@@ -97,30 +100,37 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
         tile32[r * (PD_SW / 4) + c4] = col[mad24((uint32_t)min(sy0 + r, sh - 1), (uint32_t)stride4, 0u)];
     }
   }
+  // per-tile coefficient tables: 128 column taps by threads 0..127, 16 row taps by threads 128..143 (f64 once per
+  // output column / row instead of once per thread)
+  __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
+  if (threadIdx.x < PD_W) {
+    int o; uint32_t c; lin_coef(min(x0 + (int)threadIdx.x, dw - 1), scale_x, sw, o, c);
+    xo_s[threadIdx.x] = o - sx0; xc_s[threadIdx.x] = (int)c;
+  } else if (threadIdx.x < PD_W + PD_H) {
+    const int r = threadIdx.x - PD_W;
+    int o; uint32_t c; lin_coef(min(y0 + r, dh - 1), scale_y, sh, o, c);
+    yo_s[r] = o - sy0; yc_s[r] = (int)c;
+  }
+  __syncthreads();
   const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;     // 32 quads across, 8 row pairs down
   const int x = x0 + qx * 4;
-  int o[4]; uint32_t c1[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) { lin_coef(min(x + i, dw - 1), scale_x, sw, o[i], c1[i]); o[i] -= sx0; }
-  int oy[2]; uint32_t m1v[2];
-#pragma unroll
-  for (int rr = 0; rr < 2; rr++) { lin_coef(min(y0 + qy * 2 + rr, dh - 1), scale_y, sh, oy[rr], m1v[rr]); oy[rr] -= sy0; }
-  __syncthreads();
   if (x >= dw) return;
 #pragma unroll
   for (int rr = 0; rr < 2; rr++) {
     const int y = y0 + qy * 2 + rr;
     if (y >= dh) break;
-    const uint8_t* r0 = tile + oy[rr] * PD_SW;
+    const uint8_t* r0 = tile + yo_s[qy * 2 + rr] * PD_SW;
     const uint8_t* r1 = r0 + PD_SW;
-    const uint32_t m1 = m1v[rr], m0 = 256u - m1;
+    const int m1 = yc_s[qy * 2 + rr];
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint32_t c0 = 256u - c1[i];
-      const uint32_t h0 = mad24(c0, r0[o[i]], mad24(c1[i], r0[o[i] + 1], 0u));
-      const uint32_t h1 = mad24(c0, r1[o[i]], mad24(c1[i], r1[o[i] + 1], 0u));
-      out |= (mad24(h0, m0, mad24(h1, m1, 32768u)) >> 16) << (8 * i);
+      const int o = xo_s[qx * 4 + i], c1 = xc_s[qx * 4 + i];
+      // c0*a + c1*b with c0 = 256 - c1  ==  256*a + c1*(b - a); likewise for the vertical pass
+      const int a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
+      const int h0 = mad24s(c1, b0 - a0, a0 << 8);
+      const int h1 = mad24s(c1, b1 - a1, a1 << 8);
+      out |= ((uint32_t)(mad24s(m1, h1 - h0, (h0 << 8) + 32768)) >> 16) << (8 * i);
     }
     reinterpret_cast<uint32_t*>(dimg)[mad24((uint32_t)y, (uint32_t)(dst_stride >> 2), (uint32_t)(x >> 2))] = out;
   }
@@ -737,7 +747,7 @@ __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-__constant__ int c_gauss[7] = {18, 34, 49, 55, 49, 34, 18};  // cvRound(256 * normalised exp(-x^2/8)), x=-3..3
+
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -790,19 +800,25 @@ __device__ __forceinline__ void det_sincos(double x, double* so, double* co) {
 
 #define DP_R 22                 // raw neighbourhood radius
 #define DP_N (2 * DP_R + 1)     // 45
-#define DP_STRIDE 52            // 13 dwords per staged row
+#define DP_STRIDE 52            // 13 dwords per staged row (odd dword stride: row-per-lane reads are conflict-free)
 #define DB_R 19                 // blurred radius reachable by steered taps
 #define DB_N (2 * DB_R + 1)     // 39
+#define DH_STRIDE 41            // u16 per row of the horizontal-pass buffer (odd: conflict-free row-per-lane writes)
 #define DW_PER_BLOCK 4
+
+// 7-tap sigma-2 kernel, symmetric: 18 34 49 55 49 34 18
+__device__ __forceinline__ int gauss7(int a0, int a1, int a2, int a3, int a4, int a5, int a6) {
+  return mad24s(18, a0 + a6, mad24s(34, a1 + a5, mad24s(49, a2 + a4, 55 * a3)));
+}
 
 __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) {
   __shared__ uint32_t raw32[DW_PER_BLOCK][DP_N * DP_STRIDE / 4];
-  __shared__ uint16_t hbuf[DW_PER_BLOCK][DP_N * DB_N];
+  __shared__ uint16_t hbuf[DW_PER_BLOCK][DP_N * DH_STRIDE + 1];
   __shared__ uint8_t blur[DW_PER_BLOCK][DB_N * DB_N + 3];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int f = blockIdx.y;
   const int k = blockIdx.x * DW_PER_BLOCK + wv;
-  if (k >= A.kp_count[f]) return;  // whole wave exits; no block-level barrier is used below
+  if (k >= A.kp_count[f]) return;  // whole wave exits; only wave-level synchronisation is used below
   const int64_t o = (int64_t)f * A.kcap + k;
   const uint32_t meta = A.kp_meta[o];
   const int l = (int)(meta >> 24);
@@ -812,47 +828,61 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
   const int cx = (int)rintf(A.kp_xy[2 * o] * inv), cy = (int)rintf(A.kp_xy[2 * o + 1] * inv);
   const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
   const int xs = cx - DP_R, sh = xs & 3, xa = xs - sh;
-  uint8_t* raw = reinterpret_cast<uint8_t*>(raw32[wv]);
-  for (int i = lane; i < DP_N * (DP_STRIDE / 4); i += 64) {
-    int r = i / (DP_STRIDE / 4), c4 = i - r * (DP_STRIDE / 4);
-    raw32[wv][i] = *reinterpret_cast<const uint32_t*>(img + (int64_t)(cy - DP_R + r) * L.stride + xa + c4 * 4);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#define RAW(r, c) raw[(r) * DP_STRIDE + (c) + sh]
-  // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc
-  int m10 = 0, m01 = 0;
-  for (int i = lane; i < 31 * 31; i += 64) {
-    int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
-    if (abs(u) <= c_umax[abs(v)]) {
-      int I = RAW(DP_R + v, DP_R + u);
-      m10 += u * I; m01 += v * I;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(img + xa);
+    const int stride4 = L.stride >> 2;
+    for (int i = lane; i < DP_N * (DP_STRIDE / 4); i += 64) {
+      const int r = i / (DP_STRIDE / 4), c4 = i - r * (DP_STRIDE / 4);
+      raw32[wv][i] = src[mad24((uint32_t)(cy - DP_R + r), (uint32_t)stride4, (uint32_t)c4)];
     }
+  }
+#define WAVE_LDS_SYNC()                                    \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+  __builtin_amdgcn_wave_barrier();                         \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+  WAVE_LDS_SYNC();
+  // ---- one lane per patch row: realign the row to the patch origin, then (a) orientation moments over the
+  //      radius-15 disc and (b) the horizontal 7-tap pass with a sliding window
+  int m10 = 0, m01 = 0;
+  if (lane < DP_N) {
+    const uint32_t* rp = raw32[wv] + lane * (DP_STRIDE / 4);
+    uint32_t w[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) w[j] = __builtin_amdgcn_alignbyte(rp[j + 1], rp[j], sh);
+#define RB(c) ((int)((w[(c) >> 2] >> (8 * ((c) & 3))) & 0xFFu))
+    const int v = lane - DP_R;
+    const int um = abs(v) <= 15 ? c_umax[abs(v)] : -1;   // rows outside the disc contribute nothing
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int c = DP_R - 15; c <= DP_R + 15; c++) {
+      const int u = c - DP_R;
+      const int I = abs(u) <= um ? RB(c) : 0;
+      s0 += I; s1 += u * I;
+    }
+    m10 = s1; m01 = v * s0;
+    uint16_t* hrow = hbuf[wv] + lane * DH_STRIDE;
+#pragma unroll
+    for (int c = 0; c < DB_N; c++)
+      hrow[c] = (uint16_t)gauss7(RB(c), RB(c + 1), RB(c + 2), RB(c + 3), RB(c + 4), RB(c + 5), RB(c + 6));
+#undef RB
   }
   for (int s = 32; s > 0; s >>= 1) { m10 += __shfl_xor(m10, s); m01 += __shfl_xor(m01, s); }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // ---- 7x7 Gaussian, horizontal then vertical, integer
-  for (int i = lane; i < DP_N * DB_N; i += 64) {
-    int r = i / DB_N, c = i - r * DB_N + (DP_R - DB_R);
-    int s = 0;
+  WAVE_LDS_SYNC();
+  // ---- one lane per blurred column: vertical 7-tap pass, sliding down the 45 rows
+  if (lane < DB_N) {
+    const uint16_t* hc = hbuf[wv] + lane;
+    int h[DP_N];
 #pragma unroll
-    for (int t = -3; t <= 3; t++) s += c_gauss[t + 3] * RAW(r, c + t);
-    hbuf[wv][i] = (uint16_t)s;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  for (int i = lane; i < DB_N * DB_N; i += 64) {
-    int r = i / DB_N, c = i - r * DB_N;
-    int s = 0;
+    for (int r = 0; r < DP_N; r++) h[r] = hc[r * DH_STRIDE];
 #pragma unroll
-    for (int t = -3; t <= 3; t++) s += c_gauss[t + 3] * (int)hbuf[wv][(r + (DP_R - DB_R) + t) * DB_N + c];
-    blur[wv][i] = (uint8_t)((s + 32768) >> 16);
+    for (int r = 0; r < DB_N; r++) {
+      const int rr = r + (DP_R - DB_R);
+      const int sum = gauss7(h[rr - 3], h[rr - 2], h[rr - 1], h[rr], h[rr + 1], h[rr + 2], h[rr + 3]);
+      blur[wv][r * DB_N + lane] = (uint8_t)((sum + 32768) >> 16);
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  WAVE_LDS_SYNC();
   // ---- steered BRIEF
   const float ang = angle * (float)(3.14159265358979323846 / 180.f);
   double sd, cd;
@@ -871,7 +901,7 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
   }
   if (lane < 4) reinterpret_cast<unsigned long long*>(A.desc + o * 32)[lane] = bits[lane];
   if (lane == 0) A.kp_angle[o] = angle;
-#undef RAW
+#undef WAVE_LDS_SYNC
 }
 
 }  // namespace
