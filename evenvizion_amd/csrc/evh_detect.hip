@@ -60,7 +60,7 @@ __device__ __forceinline__ int mad24s(int a, int b, int c) {   // signed a*b + c
 }
 #define PD_W 128
 #define PD_H 16
-#define PD_SW 168   // staged source row bytes (multiple of 4, >= 1.2*128 + 6)
+#define PD_SW 176   // staged source row bytes (multiple of 16, >= 1.2*128 + 2 + 15)
 #define PD_SH 24    // staged source rows (>= 1.2*16 + 3)
 // INTER_LINEAR_EXACT sampling position of destination index v: left/top tap and the 8.8 weight of the right/bottom
 // tap (the same f64 operations, in the same order, as the host reference table in evh_api.hip; samples that fall
@@ -86,18 +86,20 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
   int ox0, ox1, oy0, oy1; uint32_t cdummy;
   lin_coef(x0, scale_x, sw, ox0, cdummy); lin_coef(x1, scale_x, sw, ox1, cdummy);
   lin_coef(y0, scale_y, sh, oy0, cdummy); lin_coef(y1, scale_y, sh, oy1, cdummy);
-  const int sx0 = ox0 & ~3, sy0 = oy0;
-  const int ncol4 = (ox1 + 1 - sx0) / 4 + 1, nrow = oy1 + 2 - sy0;   // <= PD_SW/4, <= PD_SH
+  const int sx0 = ox0 & ~15, sy0 = oy0;
+  const int ncol16 = (ox1 + 1 - sx0) / 16 + 1, nrow = oy1 + 2 - sy0;   // <= PD_SW/16 = 11, <= PD_SH
   uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;   // wave-uniform 64-bit bases; per-lane offsets stay 32-bit
   const uint8_t* simg = base + src_off + sx0;
   uint8_t* dimg = base + dst_off;
   {
-    const int c4 = threadIdx.x & 63;                      // one wave stages one source row at a time
-    if (c4 < ncol4) {
-      const uint32_t* col = reinterpret_cast<const uint32_t*>(simg) + c4;
-      const int stride4 = src_stride >> 2;
-      for (int r = threadIdx.x >> 6; r < nrow; r += 4)
-        tile32[r * (PD_SW / 4) + c4] = col[mad24((uint32_t)min(sy0 + r, sh - 1), (uint32_t)stride4, 0u)];
+    // 16-byte loads: a thread moves one (row, 16-byte column) cell; 16 threads cover a source row of <= 176 bytes
+    const int c16 = threadIdx.x & 15;
+    if (c16 < ncol16) {
+      const uint4* col = reinterpret_cast<const uint4*>(simg) + c16;
+      const int stride16 = src_stride >> 4;
+      for (int r = threadIdx.x >> 4; r < nrow; r += 16)
+        *reinterpret_cast<uint4*>(&tile32[r * (PD_SW / 4) + c16 * 4]) =
+            col[mad24((uint32_t)min(sy0 + r, sh - 1), (uint32_t)stride16, 0u)];
     }
   }
   // per-tile coefficient tables: 128 column taps by threads 0..127, 16 row taps by threads 128..143 (f64 once per

@@ -133,6 +133,105 @@ __device__ void jacobi_lane(RansacLds& S, int lane) {
 #undef IC_
 }
 
+// The same eigen-solver on LDS column 0, executed by the whole wavefront for ONE matrix (inlier refit, LM solves):
+// identical arithmetic and pivot order (the first maximum in the scan order R0..R(N-2), C1..C(N-1)), but the pivot
+// search is a wave reduction, the 2N-2 element rotations run one per lane and the four index rescans run on four
+// lanes; only the c/s/t scalar chain stays serial.  Must be called by all 64 lanes.
+template <int N>
+__device__ void jacobi_wave(RansacLds& S, int lane) {
+#define A0(i, j) S.A[TRI(N, i, j) * NC]
+#define V0(i, j) S.V[((i) * N + (j)) * NC]
+#define W0(i) S.W[(i) * NC]
+#define IR0(i) S.indR[(i) * NC]
+#define IC0(i) S.indC[(i) * NC]
+  const double eps = DBL_EPSILON;
+  for (int e = lane; e < N * N; e += NL) { const int i = e / N, j = e - i * N; V0(i, j) = i == j ? 1.0 : 0.0; }
+  if (lane < N) W0(lane) = A0(lane, lane);
+  // initial indR (lanes 0..N-2) and indC (lanes N..2N-2 -> k = 1..N-1): each lane scans its own row / column
+  if (lane < N - 1) {
+    const int k = lane;
+    int m = k + 1; double mv = fabs(A0(k, m));
+    for (int i = k + 2; i < N; i++) { double val = fabs(A0(k, i)); if (mv < val) mv = val, m = i; }
+    IR0(k) = m;
+  } else if (lane >= N && lane < 2 * N - 1) {
+    const int k = lane - N + 1;
+    int m = 0; double mv = fabs(A0(0, k));
+    for (int i = 1; i < k; i++) { double val = fabs(A0(i, k)); if (mv < val) mv = val, m = i; }
+    IC0(k) = m;
+  }
+  WSYNC();
+  const int maxIters = N * N * 30;
+  for (int iters = 0; iters < maxIters; iters++) {
+    // ---- pivot: candidate j < N-1 is |A[j][indR[j]]|, candidate N-1+(i-1) is |A[indC[i]][i]| (i = 1..N-1)
+    double val = -1.0;
+    if (lane < N - 1) val = fabs(A0(lane, IR0(lane)));
+    else if (lane < 2 * N - 2) { const int i = lane - (N - 1) + 1; val = fabs(A0(IC0(i), i)); }
+    double mx = val;
+    for (int sft = 32; sft > 0; sft >>= 1) mx = fmax(mx, __shfl_xor(mx, sft));
+    int who = (val == mx) ? lane : 0x7FFFFFFF;
+    for (int sft = 32; sft > 0; sft >>= 1) who = min(who, __shfl_xor(who, sft));
+    int k, l;
+    if (who < N - 1) { k = who; l = IR0(who); }
+    else { l = who - (N - 1) + 1; k = IC0(l); }
+    const double p = A0(k, l);
+    if (fabs(p) <= eps) break;
+    const double y = (W0(l) - W0(k)) * 0.5;
+    double t = fabs(y) + hyp(p, y);
+    double sn = hyp(p, t);
+    const double c = t / sn;
+    sn = p / sn; t = (p / t) * p;
+    if (y < 0) sn = -sn, t = -t;
+    WSYNC();   // every lane has read A[k][l], W[k], W[l] before they change
+    if (lane == 0) { A0(k, l) = 0; W0(k) -= t; W0(l) += t; }
+    // ---- rotations: lane i < N rotates the A pair of index i (i != k, l); lane N+i rotates the V pair of column i
+    if (lane < N && lane != k && lane != l) {
+      const int i = lane;
+      double* p0 = i < k ? &A0(i, k) : &A0(k, i);
+      double* p1 = i < l ? &A0(i, l) : &A0(l, i);
+      const double a0 = *p0, b0 = *p1;
+      *p0 = a0 * c - b0 * sn; *p1 = a0 * sn + b0 * c;
+    } else if (lane >= N && lane < 2 * N) {
+      const int i = lane - N;
+      const double a0 = V0(k, i), b0 = V0(l, i);
+      V0(k, i) = a0 * c - b0 * sn; V0(l, i) = a0 * sn + b0 * c;
+    }
+    WSYNC();
+    // ---- rescan indR / indC of the two touched indices (four independent scans on four lanes)
+    if (lane < 4) {
+      const int idx = lane < 2 ? k : l;
+      if ((lane & 1) == 0) {
+        if (idx < N - 1) {
+          int m = idx + 1; double mv = fabs(A0(idx, m));
+          for (int i = idx + 2; i < N; i++) { double v2 = fabs(A0(idx, i)); if (mv < v2) mv = v2, m = i; }
+          IR0(idx) = m;
+        }
+      } else if (idx > 0) {
+        int m = 0; double mv = fabs(A0(0, idx));
+        for (int i = 1; i < idx; i++) { double v2 = fabs(A0(i, idx)); if (mv < v2) mv = v2, m = i; }
+        IC0(idx) = m;
+      }
+    }
+    WSYNC();
+  }
+  WSYNC();
+  // ---- sort eigenvalues (descending) with their eigenvector rows: selection sort, control flow uniform
+  for (int k = 0; k < N - 1; k++) {
+    int m = k;
+    for (int i = k + 1; i < N; i++) if (W0(m) < W0(i)) m = i;
+    WSYNC();
+    if (k != m) {
+      if (lane == 0) { double tw = W0(m); W0(m) = W0(k); W0(k) = tw; }
+      if (lane >= 1 && lane <= N) { const int i = lane - 1; double tv = V0(m, i); V0(m, i) = V0(k, i); V0(k, i) = tv; }
+    }
+    WSYNC();
+  }
+#undef A0
+#undef V0
+#undef W0
+#undef IR0
+#undef IC0
+}
+
 // de-normalise the smallest-eigenvalue eigenvector (row 8 of V) into H (runKernel's tail)
 __device__ __forceinline__ void dlt_finish(RansacLds& S, int lane, double cmx, double cmy, double smx, double smy,
                                            double cMx, double cMy, double sMx, double sMy, double* H) {
@@ -307,8 +406,8 @@ __device__ bool dlt_rows(RansacLds& S, int lane, const float* rows, int count, d
     S.A[TRI(9, j, k) * NC + 0] = s;  // column 0
   }
   WSYNC();
+  jacobi_wave<9>(S, lane);
   if (lane == 0) {
-    jacobi_lane<9>(S, 0);
     double H[9];
     dlt_finish(S, 0, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
     for (int i = 0; i < 9; i++) Hout[i] = H[i];
@@ -317,34 +416,57 @@ __device__ bool dlt_rows(RansacLds& S, int lane, const float* rows, int count, d
   return true;
 }
 
-// ---- symmetric solve / inverse through the eigen-decomposition (cv::solve / cv::invert, DECOMP_EIGEN), lane 0 ------
-__device__ void eig_solve8_lane0(RansacLds& S, const double* Ain /*LDS 64*/, const double* b /*LDS 8 or null*/,
-                                 double* x /*LDS 8 or 64*/) {
+// ---- symmetric solve / inverse through the eigen-decomposition (cv::solve / cv::invert, DECOMP_EIGEN) -------------
+// all 64 lanes; Ain / b / x live in LDS.  Back-substitution keeps the serial summation orders: lane i forms
+// s_i = (sum_j u_i[j] b[j]) / w_i, lane j accumulates x[j] += s_i u_i[j] over i ascending.
+__device__ void eig_solve8_wave(RansacLds& S, int lane, const double* Ain /*LDS 64*/, const double* b /*LDS 8 or null*/,
+                                double* x /*LDS 8 or 64*/) {
   const int N = 8;
-  for (int i = 0; i < 8; i++)
-    for (int j = i; j < 8; j++) S.A[TRI(8, i, j) * NC + 0] = Ain[i * 8 + j];
-  jacobi_lane<8>(S, 0);
+  if (lane < 36) {
+    int i = 0, e = lane;
+    while (e >= 8 - i) { e -= 8 - i; i++; }
+    const int j = i + e;
+    S.A[TRI(8, i, j) * NC] = Ain[i * 8 + j];
+  }
+  WSYNC();
+  jacobi_wave<8>(S, lane);
   double threshold = 0;
   for (int i = 0; i < 8; i++) threshold += S.W[i * NC];
   threshold *= DBL_EPSILON * 2;
-  const int nb = b ? 1 : 8;
-  for (int i = 0; i < 8 * nb; i++) x[i] = 0;
-  for (int i = 0; i < 8; i++) {
-    double wi = S.W[i * NC];
-    if (fabs(wi) <= threshold) continue;
-    wi = 1 / wi;
-    if (b) {
-      double s = 0;
-      for (int j = 0; j < 8; j++) s += S.V[(i * N + j) * NC] * b[j];
-      s *= wi;
-      for (int j = 0; j < 8; j++) x[j] = x[j] + s * S.V[(i * N + j) * NC];
-    } else {
-      for (int j = 0; j < 8; j++) {
-        double s = S.V[(i * N + j) * NC] * wi;
-        for (int r = 0; r < 8; r++) x[r * 8 + j] = x[r * 8 + j] + S.V[(i * N + r) * NC] * s;
+  if (b) {
+    // s_i on lane i (0 for skipped eigenvalues is NOT equivalent to skipping: keep a flag)
+    double si = 0; bool use = false;
+    if (lane < 8) {
+      double wi = S.W[lane * NC];
+      if (!(fabs(wi) <= threshold)) {
+        use = true;
+        wi = 1 / wi;
+        double acc = 0;
+        for (int j = 0; j < 8; j++) acc += S.V[(lane * N + j) * NC] * b[j];
+        si = acc * wi;
       }
     }
+    double xj = 0;
+    for (int i = 0; i < 8; i++) {
+      const double s_i = __shfl(si, i);
+      const int u_i = __shfl((int)use, i);
+      if (u_i && lane < 8) xj = xj + s_i * S.V[(i * N + lane) * NC];
+    }
+    if (lane < 8) x[lane] = xj;
+  } else {
+    // inverse: x[r][j] += u_i[r] * (u_i[j] / w_i) over i ascending; lane = r*8 + j
+    const int r = lane >> 3, j = lane & 7;
+    double acc = 0;
+    for (int i = 0; i < 8; i++) {
+      double wi = S.W[i * NC];
+      if (fabs(wi) <= threshold) continue;
+      wi = 1 / wi;
+      const double sj = S.V[(i * N + j) * NC] * wi;
+      acc = acc + S.V[(i * N + r) * NC] * sj;
+    }
+    x[r * 8 + j] = acc;
   }
+  WSYNC();
 }
 
 // per-point residual pieces of the refinement callback: lm[4i..] = {ww, xi, yi}; returns nothing, all lanes help
@@ -459,17 +581,18 @@ __device__ int lm_refine(RansacLds& S, int lane, const float* rows, int count, d
   WSYNC();
   int iter = 0;
   for (;;) {
-    if (lane == 0) {
-      for (int i = 0; i < 64; i++) S.Ap[i] = S.A8[i];
-      for (int i = 0; i < 8; i++) S.Ap[i * 8 + i] += S.sc[2] * S.D[i];
-      eig_solve8_lane0(S, S.Ap, S.v, S.d);
-      for (int i = 0; i < 8; i++) S.xd[i] = S.x[i] - S.d[i];
+    {
+      const int i = lane >> 3, j = lane & 7;                 // Ap = A + lambda * diag(D)
+      S.Ap[lane] = i == j ? S.A8[lane] + S.sc[2] * S.D[i] : S.A8[lane];
     }
+    WSYNC();
+    eig_solve8_wave(S, lane, S.Ap, S.v, S.d);
+    if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
     WSYNC();
     lm_points(rows, count, S.xd, lm, lane);
     __threadfence_block();
     WSYNC();
-    // ||r||_inf of the CURRENT accepted residual is needed later; the trial residual only feeds Sd
+    // trial residual -> Sd, gain ratio R; lane 0 decides, the (rare) inverse is done by the whole wave
     if (lane == 0) {
       const double Rlo = 0.25, Rhi = 0.75;
       double Sc = S.sc[0];
@@ -484,23 +607,35 @@ __device__ int lm_refine(RansacLds& S, int lane, const float* rows, int count, d
       double dS = dot8(S.d, S.tmpd);
       double R = (Sc - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
       double lambda = S.sc[2], lc = S.sc[3];
+      int need_inv = 0;
+      double nu = 0;
       if (R > Rhi) {
         lambda *= 0.5;
         if (lambda < lc) lambda = 0;
       } else if (R < Rlo) {
         double t = dot8(S.d, S.v);
-        double nu = (Sd - Sc) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+        nu = (Sd - Sc) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
         nu = fmin(fmax(nu, 2.), 10.);
-        if (lambda == 0) {
-          eig_solve8_lane0(S, S.A8, nullptr, S.Inv);
-          double maxval = DBL_EPSILON;
-          for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(S.Inv[i * 8 + i]));
-          lambda = lc = 1. / maxval;
-          nu *= 0.5;
-        }
-        lambda *= nu;
+        if (lambda == 0) need_inv = 1;
+        else lambda *= nu;
       }
-      S.sc[2] = lambda; S.sc[3] = lc;
+      S.sc[2] = lambda; S.sc[3] = lc; S.sc[4] = nu; S.sc[5] = Sd;
+      S.ib[1] = need_inv;
+    }
+    WSYNC();
+    if (S.ib[1]) {
+      eig_solve8_wave(S, lane, S.A8, nullptr, S.Inv);
+      if (lane == 0) {
+        double maxval = DBL_EPSILON;
+        for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(S.Inv[i * 8 + i]));
+        const double lam = 1. / maxval;
+        S.sc[3] = lam;                       // lc
+        S.sc[2] = lam * (S.sc[4] * 0.5);     // lambda = lc; nu *= 0.5; lambda *= nu
+      }
+      WSYNC();
+    }
+    if (lane == 0) {
+      const double Sc = S.sc[0], Sd = S.sc[5];
       S.ib[0] = Sd < Sc ? 1 : 0;
       if (Sd < Sc) {
         S.sc[0] = Sd;
