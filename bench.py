@@ -74,7 +74,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("EVH_BENCH_FORCE_DIST") == "1")
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -98,39 +104,65 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = Context(device=local_rank, max_w=w, max_h=h, max_features=args.nfeatures, max_frames=2 * B,
                   stream=stream.cuda_stream)
-    H = torch.zeros(B, 9, dtype=torch.float64, device=dev)
-    status = torch.full((B,), -1, dtype=torch.int32, device=dev)
-    gathered = torch.zeros(world * B, 9, dtype=torch.float64, device=dev) if world > 1 else None
+    # The RANSAC kernels of a step run on the context's solve stream and overlap the next step's detect kernels;
+    # results are double-buffered so that a step never overwrites what the previous step's gather still reads.
+    ctx.set_async_solve(True)
+    Hs = [torch.zeros(B, 9, dtype=torch.float64, device=dev) for _ in range(2)]
+    sts = [torch.full((B,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = torch.zeros(world * B, 9, dtype=torch.float64, device=dev) if use_dist else None
+    gstream = torch.cuda.Stream(device=dev) if use_dist else None
+    gdone = [None, None]
+    counter = [0]
 
     def step():
-        ctx.pair_homography_batch(frames, B, MODE_INDEPENDENT_PAIRS, H, status, nfeatures=args.nfeatures)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, H)   # RCCL over xGMI: gather the per-pair H records
+        k = counter[0] & 1
+        counter[0] += 1
+        if use_dist and gdone[k] is not None:
+            stream.wait_event(gdone[k])           # the gather that read this buffer two steps ago has finished
+        ctx.pair_homography_batch(frames, B, MODE_INDEPENDENT_PAIRS, Hs[k], sts[k], nfeatures=args.nfeatures)
+        if use_dist:
+            # RCCL over xGMI: gather the per-pair H records of THIS step on a side stream behind the solve
+            ctx.solve_wait(gstream.cuda_stream)
+            with torch.cuda.stream(gstream):
+                dist.all_gather_into_tensor(gathered, Hs[k])
+                ev = torch.cuda.Event()
+                ev.record(gstream)
+            gdone[k] = ev
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize(dev)
+        if saved_stdout is not None:
+            if use_dist:
+                dist.barrier()
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
         ctx.profile_read()            # drop warm-up spans
         ctx.profile_enable(True)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     stages = ctx.profile_read()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ctx.synchronize()
+    last = (counter[0] - 1) & 1
+    H, status = Hs[last], sts[last]
     st = status.cpu().numpy()
     ok_frac = float((st == 0).mean())
     total_pairs = world * B * args.steps
@@ -198,7 +230,7 @@ def main():
         }
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

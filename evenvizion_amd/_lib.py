@@ -27,6 +27,8 @@ SIGNATURES = {
     "evh_stream": (_vp, [_vp]),
     "evh_synchronize": (_i, [_vp]),
     "evh_version": (_i, []),
+    "evh_set_async_solve": (_i, [_vp, _i]),
+    "evh_solve_wait": (_i, [_vp, _vp]),
     "evh_profile_enable": (_i, [_vp, _i]),
     "evh_profile_read": (_i, [_vp, _vp, _vp]),
     "evh_profile_stage_name": (C.c_char_p, [_i]),
@@ -127,6 +129,13 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.evh_synchronize(self.h))
+
+    def set_async_solve(self, on=True):
+        self._check(self.lib.evh_set_async_solve(self.h, int(bool(on))))
+
+    def solve_wait(self, stream=None):
+        """Make `stream` (a hipStream_t handle; None = the context's main stream) wait for the pending solve."""
+        self._check(self.lib.evh_solve_wait(self.h, C.c_void_p(stream) if stream else None))
 
     def profile_enable(self, on=True):
         self._check(self.lib.evh_profile_enable(self.h, int(bool(on))))

@@ -19,16 +19,17 @@ static hipEvent_t prof_event(evh_ctx* c) {
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
 }
-EvhProfScope::EvhProfScope(evh_ctx* ctx, int stage) : c(ctx), idx(-1) {
+EvhProfScope::EvhProfScope(evh_ctx* ctx, int stage, hipStream_t on) : c(ctx), idx(-1), st(on) {
   if (!c || !c->profiling) return;
+  if (!st) st = c->stream;
   evh_ctx::ProfSpan s{stage, prof_event(c), prof_event(c)};
   if (!s.a || !s.b) return;
-  (void)hipEventRecord(s.a, c->stream);
+  (void)hipEventRecord(s.a, st);
   c->prof_spans.push_back(s);
   idx = (int)c->prof_spans.size() - 1;
 }
 EvhProfScope::~EvhProfScope() {
-  if (idx >= 0) (void)hipEventRecord(c->prof_spans[idx].b, c->stream);
+  if (idx >= 0) (void)hipEventRecord(c->prof_spans[idx].b, st);
 }
 
 namespace {
@@ -161,8 +162,37 @@ int match_pairs(evh_ctx* c, int npairs, int q0, int qstep, int t0, int tstep) {
   F.q_slot0 = q0; F.q_slot_step = qstep; F.t_slot0 = t0; F.t_slot_step = tstep;
   F.ratio = 0.5; F.min_matches = 4;  // constants.py:25,28 (LOWES_RATIO, MINIMUM_MATCHING_POINTS)
   F.pts = c->d_pts; F.pts_stride = c->kcap; F.npts = c->d_npts; F.status = c->d_pstatus; F.kcap = c->kcap;
+  // the filter overwrites the matched-row buffers the previous batch's (asynchronous) solve may still be reading
+  if (c->solve_pending) EVH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_solve_done, 0));
   EvhProfScope ps(c, EVH_ST_FILTER);
   return evh_launch_filter(c, F, npairs);
+}
+
+// entry points that reuse the pair buffers on the main stream first order themselves behind a pending async solve
+int join_solve(evh_ctx* c) {
+  if (c->solve_pending) EVH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_solve_done, 0));
+  return EVH_SUCCESS;
+}
+
+// RANSAC #1 + static filter, then compute_homography, on the solve stream when asynchronous solve is enabled
+int solve_pairs(evh_ctx* c, EvhRansacArgs R, int npairs, int stream_mode) {
+  hipStream_t main = c->stream;
+  const bool async = c->async_solve && c->solve_stream;
+  if (async) {
+    EVH_HIP(c, hipEventRecord(c->ev_match_done, main));
+    EVH_HIP(c, hipStreamWaitEvent(c->solve_stream, c->ev_match_done, 0));
+    c->stream = c->solve_stream;          // the launchers enqueue on c->stream
+  }
+  int rc;
+  { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC, c->stream); rc = evh_launch_ransac_static(c, R, npairs); }
+  if (!rc) { EvhProfScope ps(c, EVH_ST_RANSAC_FINAL, c->stream); rc = evh_launch_ransac_final(c, R, npairs, stream_mode); }
+  if (async) {
+    hipError_t e = hipEventRecord(c->ev_solve_done, c->solve_stream);
+    c->stream = main;
+    c->solve_pending = true;
+    if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+  }
+  return rc;
 }
 
 }  // namespace
@@ -245,6 +275,9 @@ void evh_destroy(evh_ctx* c) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : c->prof_pool) (void)hipEventDestroy(e);
+  if (c->solve_stream) { (void)hipStreamSynchronize(c->solve_stream); (void)hipStreamDestroy(c->solve_stream); }
+  if (c->ev_match_done) (void)hipEventDestroy(c->ev_match_done);
+  if (c->ev_solve_done) (void)hipEventDestroy(c->ev_solve_done);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -270,6 +303,7 @@ const char* evh_profile_stage_name(int stage) {
 int evh_profile_read(evh_ctx* c, float* h_total_ms, int* h_counts) {
   if (!c || !h_total_ms || !h_counts) return evh_fail(c, EVH_ERR_INVALID, "evh_profile_read: bad argument");
   EVH_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->solve_stream) EVH_HIP(c, hipStreamSynchronize(c->solve_stream));
   for (int i = 0; i < EVH_NSTAGES; i++) { h_total_ms[i] = 0.f; h_counts[i] = 0; }
   for (auto& s : c->prof_spans) {
     float ms = 0.f;
@@ -285,6 +319,26 @@ void* evh_stream(const evh_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int evh_synchronize(evh_ctx* c) {
   if (!c) return EVH_ERR_INVALID;
   EVH_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->solve_stream) EVH_HIP(c, hipStreamSynchronize(c->solve_stream));
+  c->solve_pending = false;
+  return EVH_SUCCESS;
+}
+
+int evh_set_async_solve(evh_ctx* c, int on) {
+  if (!c) return EVH_ERR_INVALID;
+  if (on && !c->solve_stream) {
+    EVH_HIP(c, hipStreamCreateWithFlags(&c->solve_stream, hipStreamNonBlocking));
+    EVH_HIP(c, hipEventCreateWithFlags(&c->ev_match_done, hipEventDisableTiming));
+    EVH_HIP(c, hipEventCreateWithFlags(&c->ev_solve_done, hipEventDisableTiming));
+  }
+  if (!on && c->solve_stream) { EVH_HIP(c, hipStreamSynchronize(c->solve_stream)); c->solve_pending = false; }
+  c->async_solve = on != 0;
+  return EVH_SUCCESS;
+}
+
+int evh_solve_wait(evh_ctx* c, void* stream) {
+  if (!c) return EVH_ERR_INVALID;
+  if (c->solve_pending) EVH_HIP(c, hipStreamWaitEvent(stream ? (hipStream_t)stream : c->stream, c->ev_solve_done, 0));
   return EVH_SUCCESS;
 }
 
@@ -432,6 +486,7 @@ int evh_find_homography_ransac(evh_ctx* c, const float* d_pts, int n, double thr
   if (!c || (!d_pts && n > 0) || n < 0 || !h_H || !h_found) return evh_fail(c, EVH_ERR_INVALID, "evh_find_homography_ransac: bad argument");
   if (n > c->kcap * c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "evh_find_homography_ransac: too many rows");
   if (((uintptr_t)d_pts) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_pts must be 16-byte aligned");
+  { int jr = join_solve(c); if (jr) return jr; }
   // scratch: the per-pair buffers viewed as one big problem
   EvhRansacArgs R{};
   R.pts = const_cast<float*>(d_pts); R.n_fixed = n; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = 0;
@@ -455,6 +510,7 @@ int evh_static_filter(evh_ctx* c, const double* h_H, const float* d_pts, int n, 
   if (!c || !h_H || (!d_pts && n > 0) || !d_out_pts || !h_count || n < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_static_filter: bad argument");
   if (n > c->kcap * c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "evh_static_filter: too many rows");
   if ((((uintptr_t)d_pts) | ((uintptr_t)d_out_pts)) & 15) return evh_fail(c, EVH_ERR_INVALID, "row buffers must be 16-byte aligned");
+  { int jr = join_solve(c); if (jr) return jr; }
   EVH_HIP(c, hipMemcpyAsync(c->d_small, h_H, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int* d_cnt = reinterpret_cast<int*>(c->d_small + 16);
   int rc = evh_launch_static_filter(c, c->d_small, d_pts, n, reinterpret_cast<int*>(c->d_lm), d_out_pts, d_cnt);
@@ -477,11 +533,8 @@ int evh_pair_homography_batch(evh_ctx* c, const uint8_t* d_frames, int npairs, i
   else rc = match_pairs(c, npairs, 1, 1, 0, 1);
   if (rc) return rc;
   EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
-  { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC); rc = evh_launch_ransac_static(c, R, npairs); }
-  if (rc) return rc;
   R.H = d_H; R.out_status = d_status;
-  EvhProfScope ps(c, EVH_ST_RANSAC_FINAL);
-  return evh_launch_ransac_final(c, R, npairs, mode == EVH_MODE_STREAM);
+  return solve_pairs(c, R, npairs, mode == EVH_MODE_STREAM);
 }
 
 int evh_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
@@ -495,19 +548,17 @@ int evh_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nframes
   if (rc) return rc;
   if ((rc = match_pairs(c, npairs, 1, 1, 0, 1))) return rc;
   EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
-  { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC); rc = evh_launch_ransac_static(c, R, npairs); }
-  if (rc) return rc;
   R.H = d_H; R.out_status = d_status;
   if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
   R.state_out = d_state_out;
-  EvhProfScope ps(c, EVH_ST_RANSAC_FINAL);
-  return evh_launch_ransac_final(c, R, npairs, 1);
+  return solve_pairs(c, R, npairs, 1);
 }
 
 int evh_match_static_from_slots(evh_ctx* c, int cur_slot, int prev_slot, float* h_pts, int cap, int* h_count, int* h_status) {
   if (!c || !h_count || !h_status || cur_slot < 0 || prev_slot < 0 || cur_slot >= c->nframes_resident ||
       prev_slot >= c->nframes_resident)
     return evh_fail(c, EVH_ERR_INVALID, "evh_match_static_from_slots: bad argument");
+  { int jr = join_solve(c); if (jr) return jr; }
   int rc = match_pairs(c, 1, cur_slot, 0, prev_slot, 0);
   if (rc) return rc;
   EvhRansacArgs R = pair_ransac_args(c, 3.0, 2000, 0.995, 0);  // constants.py:22 THRESHOLD_FOR_FIND_HOMOGRAPHY
@@ -527,6 +578,7 @@ int evh_match_static_from_slots(evh_ctx* c, int cur_slot, int prev_slot, float* 
 int evh_compute_homography(evh_ctx* c, const float* h_pts, int n, const double* h_Hsup, double* h_H, int* h_status) {
   if (!c || (!h_pts && n > 0) || !h_H || !h_status || n < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_compute_homography: bad argument");
   if (n > c->kcap) return evh_fail(c, EVH_ERR_CAPACITY, "evh_compute_homography: too many rows");
+  { int jr = join_solve(c); if (jr) return jr; }
   const int zero = 0;
   EVH_HIP(c, hipMemcpyAsync(c->d_pts2, h_pts, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   EVH_HIP(c, hipMemcpyAsync(c->d_npts2, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));

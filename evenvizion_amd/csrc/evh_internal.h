@@ -38,6 +38,11 @@ struct evh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // asynchronous solve: the RANSAC kernels of a batch run on a second stream so that they overlap the next
+  // batch's detect kernels (they occupy one wave per SIMD and are latency-bound)
+  hipStream_t solve_stream = nullptr;
+  hipEvent_t ev_match_done = nullptr, ev_solve_done = nullptr;
+  bool async_solve = false, solve_pending = false;
   int max_w = 0, max_h = 0, max_features = 0, max_frames = 0;
   int kcap = 0;  // keypoint rows per frame slot
   EvhGeom g{};
@@ -90,8 +95,8 @@ enum { EVH_ST_GRAY = 0, EVH_ST_PYRAMID, EVH_ST_FAST, EVH_ST_SELECT, EVH_ST_DESCR
        EVH_ST_RANSAC_STATIC, EVH_ST_RANSAC_FINAL };
 // RAII bracket: records an event pair around the launches issued while it is alive (no-op unless profiling)
 struct EvhProfScope {
-  evh_ctx* c; int idx;
-  EvhProfScope(evh_ctx* ctx, int stage);
+  evh_ctx* c; int idx; hipStream_t st;
+  EvhProfScope(evh_ctx* ctx, int stage, hipStream_t on = nullptr);
   ~EvhProfScope();
 };
 

@@ -4,10 +4,10 @@
 // get_largest_group_points (utils.py:258-325), compute_homography (utils.py:328-363), matrix_superposition
 // (utils.py:118-145).
 //
-// One wavefront (64 lanes) per frame pair.  RANSAC hypotheses are evaluated 64 at a time -- one 4-point
-// hypothesis per lane: the sample sequence of the fixed-seed multiply-with-carry generator is advanced by every
-// lane identically, each lane keeps its own quadruple, solves its own normalised DLT (9x9 Jacobi eigen-solver on
-// a lane-private LDS column, f64) and counts its inliers over all points; a sequential replay in sample order
+// One wavefront (64 lanes) per frame pair.  RANSAC hypotheses are evaluated four at a time -- one 4-point
+// hypothesis per 16-lane group: the sample sequence of the fixed-seed multiply-with-carry generator is advanced
+// by every lane identically, each group keeps its own quadruple, solves its normalised DLT (9x9 Jacobi
+// eigen-solver, f64, cooperative inside the group) and counts its inliers; a sequential replay in sample order
 // then applies "strictly more inliers wins" and the adaptive iteration bound exactly like a serial RANSAC.
 // All floating-point sums keep a fixed order (-ffp-contract=off); f64 throughout the solves, f32 for the
 // reprojection error, as the operator being replaced.
@@ -20,14 +20,16 @@ namespace {
 
 #define WSYNC() __syncthreads()
 #define NL 64          // lanes of the wavefront
-#define NC 32          // hypotheses evaluated per chunk = lane-private matrix columns held in LDS
+#define NG 4           // lane groups of 16: one 4-point hypothesis (or one refit / LM matrix) per group
+#define GL 16          // lanes per group
+#define NC NG          // LDS matrix columns (one per group)
 // upper-triangle index of (i, j), i <= j, of an N x N symmetric matrix (the eigen-solver only touches i <= j)
 __device__ __forceinline__ int tri_index(int N, int i, int j) { return i * N - (i * (i - 1)) / 2 + (j - i); }
 #define TRI(N, i, j) tri_index((N), (i), (j))
 
 struct RansacLds {
-  double A[45 * NC];   // column-private symmetric 9x9 (or 8x8), upper triangle, element-major: A[TRI(i,j)*NC + col]
-  double V[81 * NC];   // column-private eigenvectors (rows), element-major
+  double A[45 * NC];   // per-group symmetric 9x9 (or 8x8), upper triangle, element-major: A[TRI(i,j)*NC + group]
+  double V[81 * NC];   // per-group eigenvectors (rows), element-major
   double W[9 * NC];
   int indR[9 * NC];
   int indC[9 * NC];
@@ -45,161 +47,90 @@ __device__ __forceinline__ double hyp(double a, double b) {
   return 0;
 }
 
-// Jacobi eigen-solver on LDS column `lane` (< NC). Eigenvalues descending in W, eigenvectors = rows of V.
+// Symmetric eigen-solver (Jacobi with largest-pivot selection, eigenvalues sorted descending, eigenvectors = rows
+// of V), one matrix per 16-lane group, up to four groups of a wavefront at once.  Arithmetic and pivot order are
+// those of the serial algorithm (the first maximum in the scan order R0..R(N-2), C1..C(N-1)); inside a group the
+// pivot search is a 16-lane reduction, the 2N-2 element rotations run one per lane and the four index rescans on
+// four lanes; only the c/s/t scalar chain is serial.  Must be called by all 64 lanes; `active` is group-uniform.
 template <int N>
-__device__ void jacobi_lane(RansacLds& S, int lane) {
-#define A_(i, j) S.A[TRI(N, i, j) * NC + lane]
-#define V_(i, j) S.V[((i) * N + (j)) * NC + lane]
-#define W_(i) S.W[(i) * NC + lane]
-#define IR_(i) S.indR[(i) * NC + lane]
-#define IC_(i) S.indC[(i) * NC + lane]
+__device__ void jacobi_group(RansacLds& S, int lane, bool active) {
+  const int g = lane >> 4, gl = lane & 15;
+#define A0(i, j) S.A[TRI(N, i, j) * NC + g]
+#define V0(i, j) S.V[((i) * N + (j)) * NC + g]
+#define W0(i) S.W[(i) * NC + g]
+#define IR0(i) S.indR[(i) * NC + g]
+#define IC0(i) S.indC[(i) * NC + g]
   const double eps = DBL_EPSILON;
-  int i, j, k, m;
-  for (i = 0; i < N; i++) { for (j = 0; j < N; j++) V_(i, j) = 0; V_(i, i) = 1; }
-  double mv = 0;
-  for (k = 0; k < N; k++) {
-    W_(k) = A_(k, k);
-    if (k < N - 1) {
-      for (m = k + 1, mv = fabs(A_(k, m)), i = k + 2; i < N; i++) {
-        double val = fabs(A_(k, i));
-        if (mv < val) mv = val, m = i;
-      }
-      IR_(k) = m;
+  if (active) {
+    for (int e = gl; e < N * N; e += GL) { const int i = e / N, j = e - i * N; V0(i, j) = i == j ? 1.0 : 0.0; }
+    if (gl < N) W0(gl) = A0(gl, gl);
+    // initial indR (lanes 0..N-2 -> k) and indC (lanes 8.. -> k = 1..N-1): each lane scans its own row / column
+    if (gl < N - 1) {
+      const int k = gl;
+      int m = k + 1; double mv = fabs(A0(k, m));
+      for (int i = k + 2; i < N; i++) { double val = fabs(A0(k, i)); if (mv < val) mv = val, m = i; }
+      IR0(k) = m;
+    } else if (gl >= 8 && gl < 8 + N - 1) {
+      const int k = gl - 8 + 1;
+      int m = 0; double mv = fabs(A0(0, k));
+      for (int i = 1; i < k; i++) { double val = fabs(A0(i, k)); if (mv < val) mv = val, m = i; }
+      IC0(k) = m;
     }
-    if (k > 0) {
-      for (m = 0, mv = fabs(A_(0, k)), i = 1; i < k; i++) {
-        double val = fabs(A_(i, k));
-        if (mv < val) mv = val, m = i;
-      }
-      IC_(k) = m;
-    }
-  }
-  const int maxIters = N * N * 30;
-  for (int iters = 0; iters < maxIters; iters++) {
-    for (k = 0, mv = fabs(A_(0, IR_(0))), i = 1; i < N - 1; i++) {
-      double val = fabs(A_(i, IR_(i)));
-      if (mv < val) mv = val, k = i;
-    }
-    int l = IR_(k);
-    for (i = 1; i < N; i++) {
-      double val = fabs(A_(IC_(i), i));
-      if (mv < val) mv = val, k = IC_(i), l = i;
-    }
-    double p = A_(k, l);
-    if (fabs(p) <= eps) break;
-    double y = (W_(l) - W_(k)) * 0.5;
-    double t = fabs(y) + hyp(p, y);
-    double s = hyp(p, t);
-    double c = t / s;
-    s = p / s; t = (p / t) * p;
-    if (y < 0) s = -s, t = -t;
-    A_(k, l) = 0;
-    W_(k) -= t;
-    W_(l) += t;
-    double a0, b0;
-#define ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
-    for (i = 0; i < k; i++) ROT(A_(i, k), A_(i, l));
-    for (i = k + 1; i < l; i++) ROT(A_(k, i), A_(i, l));
-    for (i = l + 1; i < N; i++) ROT(A_(k, i), A_(l, i));
-    for (i = 0; i < N; i++) ROT(V_(k, i), V_(l, i));
-#undef ROT
-    for (j = 0; j < 2; j++) {
-      int idx = j == 0 ? k : l;
-      if (idx < N - 1) {
-        for (m = idx + 1, mv = fabs(A_(idx, m)), i = idx + 2; i < N; i++) {
-          double val = fabs(A_(idx, i));
-          if (mv < val) mv = val, m = i;
-        }
-        IR_(idx) = m;
-      }
-      if (idx > 0) {
-        for (m = 0, mv = fabs(A_(0, idx)), i = 1; i < idx; i++) {
-          double val = fabs(A_(i, idx));
-          if (mv < val) mv = val, m = i;
-        }
-        IC_(idx) = m;
-      }
-    }
-  }
-  for (k = 0; k < N - 1; k++) {
-    m = k;
-    for (i = k + 1; i < N; i++) if (W_(m) < W_(i)) m = i;
-    if (k != m) {
-      double tw = W_(m); W_(m) = W_(k); W_(k) = tw;
-      for (i = 0; i < N; i++) { double tv = V_(m, i); V_(m, i) = V_(k, i); V_(k, i) = tv; }
-    }
-  }
-#undef IR_
-#undef IC_
-}
-
-// The same eigen-solver on LDS column 0, executed by the whole wavefront for ONE matrix (inlier refit, LM solves):
-// identical arithmetic and pivot order (the first maximum in the scan order R0..R(N-2), C1..C(N-1)), but the pivot
-// search is a wave reduction, the 2N-2 element rotations run one per lane and the four index rescans run on four
-// lanes; only the c/s/t scalar chain stays serial.  Must be called by all 64 lanes.
-template <int N>
-__device__ void jacobi_wave(RansacLds& S, int lane) {
-#define A0(i, j) S.A[TRI(N, i, j) * NC]
-#define V0(i, j) S.V[((i) * N + (j)) * NC]
-#define W0(i) S.W[(i) * NC]
-#define IR0(i) S.indR[(i) * NC]
-#define IC0(i) S.indC[(i) * NC]
-  const double eps = DBL_EPSILON;
-  for (int e = lane; e < N * N; e += NL) { const int i = e / N, j = e - i * N; V0(i, j) = i == j ? 1.0 : 0.0; }
-  if (lane < N) W0(lane) = A0(lane, lane);
-  // initial indR (lanes 0..N-2) and indC (lanes N..2N-2 -> k = 1..N-1): each lane scans its own row / column
-  if (lane < N - 1) {
-    const int k = lane;
-    int m = k + 1; double mv = fabs(A0(k, m));
-    for (int i = k + 2; i < N; i++) { double val = fabs(A0(k, i)); if (mv < val) mv = val, m = i; }
-    IR0(k) = m;
-  } else if (lane >= N && lane < 2 * N - 1) {
-    const int k = lane - N + 1;
-    int m = 0; double mv = fabs(A0(0, k));
-    for (int i = 1; i < k; i++) { double val = fabs(A0(i, k)); if (mv < val) mv = val, m = i; }
-    IC0(k) = m;
   }
   WSYNC();
+  bool done = !active;
   const int maxIters = N * N * 30;
   for (int iters = 0; iters < maxIters; iters++) {
-    // ---- pivot: candidate j < N-1 is |A[j][indR[j]]|, candidate N-1+(i-1) is |A[indC[i]][i]| (i = 1..N-1)
+    if (__ballot(!done) == 0ull) break;
+    // ---- pivot: lane j < N-1 holds |A[j][indR[j]]|, lane 8+(i-1) holds |A[indC[i]][i]| (i = 1..N-1); lane order =
+    //      scan order, so "first maximum" = smallest lane among the equal maxima
     double val = -1.0;
-    if (lane < N - 1) val = fabs(A0(lane, IR0(lane)));
-    else if (lane < 2 * N - 2) { const int i = lane - (N - 1) + 1; val = fabs(A0(IC0(i), i)); }
+    if (!done) {
+      if (gl < N - 1) val = fabs(A0(gl, IR0(gl)));
+      else if (gl >= 8 && gl < 8 + N - 1) { const int i = gl - 8 + 1; val = fabs(A0(IC0(i), i)); }
+    }
     double mx = val;
-    for (int sft = 32; sft > 0; sft >>= 1) mx = fmax(mx, __shfl_xor(mx, sft));
-    int who = (val == mx) ? lane : 0x7FFFFFFF;
-    for (int sft = 32; sft > 0; sft >>= 1) who = min(who, __shfl_xor(who, sft));
-    int k, l;
-    if (who < N - 1) { k = who; l = IR0(who); }
-    else { l = who - (N - 1) + 1; k = IC0(l); }
-    const double p = A0(k, l);
-    if (fabs(p) <= eps) break;
-    const double y = (W0(l) - W0(k)) * 0.5;
-    double t = fabs(y) + hyp(p, y);
-    double sn = hyp(p, t);
-    const double c = t / sn;
-    sn = p / sn; t = (p / t) * p;
-    if (y < 0) sn = -sn, t = -t;
+    for (int sft = 8; sft > 0; sft >>= 1) mx = fmax(mx, __shfl_xor(mx, sft));
+    int who = (val == mx) ? gl : 0x7FFFFFFF;
+    for (int sft = 8; sft > 0; sft >>= 1) who = min(who, __shfl_xor(who, sft));
+    int k = 0, l = 1;
+    double c = 1, sn = 0, t = 0;
+    if (!done) {
+      if (who < 8) { k = who; l = IR0(who); }
+      else { l = who - 8 + 1; k = IC0(l); }
+      const double p = A0(k, l);
+      if (fabs(p) <= eps) done = true;
+      else {
+        const double y = (W0(l) - W0(k)) * 0.5;
+        t = fabs(y) + hyp(p, y);
+        sn = hyp(p, t);
+        c = t / sn;
+        sn = p / sn; t = (p / t) * p;
+        if (y < 0) sn = -sn, t = -t;
+      }
+    }
     WSYNC();   // every lane has read A[k][l], W[k], W[l] before they change
-    if (lane == 0) { A0(k, l) = 0; W0(k) -= t; W0(l) += t; }
-    // ---- rotations: lane i < N rotates the A pair of index i (i != k, l); lane N+i rotates the V pair of column i
-    if (lane < N && lane != k && lane != l) {
-      const int i = lane;
-      double* p0 = i < k ? &A0(i, k) : &A0(k, i);
-      double* p1 = i < l ? &A0(i, l) : &A0(l, i);
-      const double a0 = *p0, b0 = *p1;
-      *p0 = a0 * c - b0 * sn; *p1 = a0 * sn + b0 * c;
-    } else if (lane >= N && lane < 2 * N) {
-      const int i = lane - N;
-      const double a0 = V0(k, i), b0 = V0(l, i);
-      V0(k, i) = a0 * c - b0 * sn; V0(l, i) = a0 * sn + b0 * c;
+    if (!done) {
+      if (gl == 0) { A0(k, l) = 0; W0(k) -= t; W0(l) += t; }
+      // rotations: lane r < N rotates the V pair of column r; lane N+j rotates the A pair of the j-th index != k, l
+      if (gl < N) {
+        const double a0 = V0(k, gl), b0 = V0(l, gl);
+        V0(k, gl) = a0 * c - b0 * sn; V0(l, gl) = a0 * sn + b0 * c;
+      } else if (gl - N < N - 2) {
+        int i = gl - N;
+        if (i >= k) i++;
+        if (i >= l) i++;
+        double* p0 = i < k ? &A0(i, k) : &A0(k, i);
+        double* p1 = i < l ? &A0(i, l) : &A0(l, i);
+        const double a0 = *p0, b0 = *p1;
+        *p0 = a0 * c - b0 * sn; *p1 = a0 * sn + b0 * c;
+      }
     }
     WSYNC();
     // ---- rescan indR / indC of the two touched indices (four independent scans on four lanes)
-    if (lane < 4) {
-      const int idx = lane < 2 ? k : l;
-      if ((lane & 1) == 0) {
+    if (!done && gl < 4) {
+      const int idx = gl < 2 ? k : l;
+      if ((gl & 1) == 0) {
         if (idx < N - 1) {
           int m = idx + 1; double mv = fabs(A0(idx, m));
           for (int i = idx + 2; i < N; i++) { double v2 = fabs(A0(idx, i)); if (mv < v2) mv = v2, m = i; }
@@ -214,14 +145,14 @@ __device__ void jacobi_wave(RansacLds& S, int lane) {
     WSYNC();
   }
   WSYNC();
-  // ---- sort eigenvalues (descending) with their eigenvector rows: selection sort, control flow uniform
+  // ---- sort eigenvalues (descending) with their eigenvector rows: selection sort
   for (int k = 0; k < N - 1; k++) {
     int m = k;
-    for (int i = k + 1; i < N; i++) if (W0(m) < W0(i)) m = i;
+    if (active) for (int i = k + 1; i < N; i++) if (W0(m) < W0(i)) m = i;
     WSYNC();
-    if (k != m) {
-      if (lane == 0) { double tw = W0(m); W0(m) = W0(k); W0(k) = tw; }
-      if (lane >= 1 && lane <= N) { const int i = lane - 1; double tv = V0(m, i); V0(m, i) = V0(k, i); V0(k, i) = tv; }
+    if (active && k != m) {
+      if (gl == 0) { double tw = W0(m); W0(m) = W0(k); W0(k) = tw; }
+      if (gl >= 1 && gl <= N) { const int i = gl - 1; double tv = V0(m, i); V0(m, i) = V0(k, i); V0(k, i) = tv; }
     }
     WSYNC();
   }
@@ -232,13 +163,12 @@ __device__ void jacobi_wave(RansacLds& S, int lane) {
 #undef IC0
 }
 
-// de-normalise the smallest-eigenvalue eigenvector (row 8 of V) into H (runKernel's tail)
-__device__ __forceinline__ void dlt_finish(RansacLds& S, int lane, double cmx, double cmy, double smx, double smy,
+// de-normalise the smallest-eigenvalue eigenvector (row 8 of V, column `col`) into H (runKernel's tail)
+__device__ __forceinline__ void dlt_finish(RansacLds& S, int col, double cmx, double cmy, double smx, double smy,
                                            double cMx, double cMy, double sMx, double sMy, double* H) {
-  const int N = 9;
   double H0[9];
 #pragma unroll
-  for (int i = 0; i < 9; i++) H0[i] = V_(8, i);
+  for (int i = 0; i < 9; i++) H0[i] = S.V[((8) * 9 + i) * NC + col];
   const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
   const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
   double Ht[9], H1[9];
@@ -257,10 +187,22 @@ __device__ __forceinline__ void dlt_finish(RansacLds& S, int lane, double cmx, d
   for (int i = 0; i < 9; i++) H[i] = H1[i] * inv;
 }
 
-// normalised DLT of the calling lane's own 4 correspondences (M -> m). returns false when degenerate.
-__device__ bool dlt4_lane(RansacLds& S, int lane, const float* Mx, const float* My, const float* mx, const float* my,
-                          double* H) {
-  const int N = 9;
+// one entry (j, k) of L^T L contributed by a normalised correspondence (x, y) <- (X, Y)
+__device__ __forceinline__ double ltl_term(int j, int k, double x, double y, double X, double Y) {
+  const double nxX = -x * X, nxY = -x * Y, nyX = -y * X, nyY = -y * Y;
+  // Lx = {X, Y, 1, 0, 0, 0, -xX, -xY, -x}; Ly = {0, 0, 0, X, Y, 1, -yX, -yY, -y}
+#define LXS(q) ((q) == 0 ? X : (q) == 1 ? Y : (q) == 2 ? 1.0 : (q) < 6 ? 0.0 : (q) == 6 ? nxX : (q) == 7 ? nxY : -x)
+#define LYS(q) ((q) < 3 ? 0.0 : (q) == 3 ? X : (q) == 4 ? Y : (q) == 5 ? 1.0 : (q) == 6 ? nyX : (q) == 7 ? nyY : -y)
+  return LXS(j) * LXS(k) + LYS(j) * LYS(k);
+#undef LXS
+#undef LYS
+}
+
+// normalised DLT of each group's own 4 correspondences (M -> m): every lane of a group holds the same 4 rows.
+// `valid` is group-uniform; returns (group-uniform) whether a model was produced; H valid on every lane of the group.
+__device__ bool dlt4_group(RansacLds& S, int lane, bool valid, const float* Mx, const float* My, const float* mx,
+                           const float* my, double* H) {
+  const int g = lane >> 4, gl = lane & 15;
   double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) { cmx += mx[i]; cmy += my[i]; cMx += Mx[i]; cMy += My[i]; }
@@ -270,38 +212,26 @@ __device__ bool dlt4_lane(RansacLds& S, int lane, const float* Mx, const float* 
     smx += fabs(mx[i] - cmx); smy += fabs(my[i] - cmy);
     sMx += fabs(Mx[i] - cMx); sMy += fabs(My[i] - cMy);
   }
-  if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON)
-    return false;
-  smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
-  double L[45];
+  const bool ok = valid && !(fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON ||
+                             fabs(sMy) < DBL_EPSILON);
+  if (ok) {
+    smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
+    for (int e = gl; e < 45; e += GL) {          // L^T L upper triangle, entry e <-> (j, k), rows summed in order
+      int j = 0, r = e;
+      while (r >= 9 - j) { r -= 9 - j; j++; }
+      const int k = j + r;
+      double acc = 0;
 #pragma unroll
-  for (int e = 0; e < 45; e++) L[e] = 0;
-#pragma unroll 1
-  for (int i = 0; i < 4; i++) {
-    double x = (mx[i] - cmx) * smx, y = (my[i] - cmy) * smy;
-    double X = (Mx[i] - cMx) * sMx, Y = (My[i] - cMy) * sMy;
-    const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-    const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-    int e = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++)
-#pragma unroll
-      for (int k = j; k < 9; k++, e++) L[e] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+      for (int i = 0; i < 4; i++)
+        acc += ltl_term(j, k, (mx[i] - cmx) * smx, (my[i] - cmy) * smy, (Mx[i] - cMx) * sMx, (My[i] - cMy) * sMy);
+      S.A[TRI(9, j, k) * NC + g] = acc;
+    }
   }
-  {
-    int e = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++)
-#pragma unroll
-      for (int k = j; k < 9; k++, e++) A_(j, k) = L[e];
-  }
-  jacobi_lane<9>(S, lane);
-  dlt_finish(S, lane, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
-  return true;
+  WSYNC();
+  jacobi_group<9>(S, lane, ok);
+  if (ok) dlt_finish(S, g, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
+  return ok;
 }
-#undef A_
-#undef V_
-#undef W_
 
 struct Rng {  // multiply-with-carry generator, seeded with all ones for every findHomography call
   unsigned long long state;
@@ -406,7 +336,7 @@ __device__ bool dlt_rows(RansacLds& S, int lane, const float* rows, int count, d
     S.A[TRI(9, j, k) * NC + 0] = s;  // column 0
   }
   WSYNC();
-  jacobi_wave<9>(S, lane);
+  jacobi_group<9>(S, lane, lane < GL);
   if (lane == 0) {
     double H[9];
     dlt_finish(S, 0, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
@@ -429,7 +359,7 @@ __device__ void eig_solve8_wave(RansacLds& S, int lane, const double* Ain /*LDS 
     S.A[TRI(8, i, j) * NC] = Ain[i * 8 + j];
   }
   WSYNC();
-  jacobi_wave<8>(S, lane);
+  jacobi_group<8>(S, lane, lane < GL);
   double threshold = 0;
   for (int i = 0; i < 8; i++) threshold += S.W[i * NC];
   threshold *= DBL_EPSILON * 2;
@@ -691,9 +621,10 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
   int niters = max(maxItersArg, 1), maxGood = 0, iter = 0, run = 0;
   bool stop = false, any_found = false;
   while (!stop && iter < niters) {
-    // every lane advances the generator identically through NC quadruples; lane h < NC keeps quadruple #h
+    // every lane advances the generator identically through NG quadruples; the lanes of group h keep quadruple #h
+    const int grp = lane >> 4;
     int my[4] = {0, 1, 2, 3};
-    for (int h = 0; h < NC; h++) {
+    for (int h = 0; h < NG; h++) {
       int q[4];
       for (int i = 0; i < 4;) {
         int idx_i;
@@ -705,7 +636,7 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
         }
         i++;
       }
-      if (h == lane) { my[0] = q[0]; my[1] = q[1]; my[2] = q[2]; my[3] = q[3]; }
+      if (h == grp) { my[0] = q[0]; my[1] = q[1]; my[2] = q[2]; my[3] = q[3]; }
     }
     float Mx[4], My[4], mx[4], my_[4];
 #pragma unroll
@@ -713,26 +644,24 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
       const float4 r = *reinterpret_cast<const float4*>(rows + 4 * my[i]);
       Mx[i] = r.x; My[i] = r.y; mx[i] = r.z; my_[i] = r.w;
     }
-    const bool valid = lane < NC && check_subset4(Mx, My, mx, my_);
+    const bool valid = check_subset4(Mx, My, mx, my_);
     double H[9];
-    bool ok = false;
+    const bool ok = dlt4_group(S, lane, valid, Mx, My, mx, my_, H);
     int good = 0;
-    if (valid) {
-      ok = dlt4_lane(S, lane, Mx, My, mx, my_, H);
-      if (ok) {
-        float Hf[8];
+    if (ok) {   // the 16 lanes of the group split the points; integer count, order-free
+      float Hf[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
-        for (int i = 0; i < n; i++) {
-          const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
-          good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
-        }
+      for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+      for (int i = lane & 15; i < n; i += GL) {
+        const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+        good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
       }
     }
+    for (int sft = 8; sft > 0; sft >>= 1) good += __shfl_xor(good, sft);
     const unsigned long long vmask = __ballot(valid), okmask = __ballot(ok);
     // sequential replay in sample order
-    for (int h = 0; h < NC; h++) {
-      if (!((vmask >> h) & 1ull)) {  // rejected sample: counts towards the 10000-attempt bound of one draw
+    for (int h = 0; h < NG; h++) {
+      if (!((vmask >> (GL * h)) & 1ull)) {  // rejected sample: counts towards the 10000-attempt bound of one draw
         if (++run >= 10000) { stop = true; break; }
         continue;
       }
@@ -740,11 +669,11 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
       if (iter >= niters) { stop = true; break; }
       iter++;
       any_found = true;
-      if (!((okmask >> h) & 1ull)) continue;
-      const int g = __shfl(good, h);
+      if (!((okmask >> (GL * h)) & 1ull)) continue;
+      const int g = __shfl(good, GL * h);
       if (g > max(maxGood, 3)) {
         maxGood = g;
-        if (lane == h) {
+        if (lane == GL * h) {
 #pragma unroll
           for (int i = 0; i < 9; i++) S.bestH[i] = H[i];
         }

@@ -61,8 +61,14 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
 void evh_destroy(evh_ctx* ctx);
 const char* evh_last_error_string(const evh_ctx* ctx); /* ctx may be NULL: last error of evh_create */
 void* evh_stream(const evh_ctx* ctx);                  /* the hipStream_t all kernels are launched on */
-int evh_synchronize(evh_ctx* ctx);
+int evh_synchronize(evh_ctx* ctx);                     /* waits for the main AND the solve stream */
 int evh_version(void);
+/* Asynchronous solve (default off): the RANSAC kernels of evh_pair_homography_batch / evh_stream_homography_batch
+ * are enqueued on a second, context-owned stream behind an event, so that they overlap the NEXT batch's detect
+ * kernels (they are latency-bound and occupy one wave per SIMD).  d_H / d_status are then complete only after
+ * evh_synchronize(), or on a stream that has called evh_solve_wait (stream = NULL: the context's main stream). */
+int evh_set_async_solve(evh_ctx* ctx, int on);
+int evh_solve_wait(evh_ctx* ctx, void* stream);
 
 /* ---- per-stage device timing (measurement aid, used by bench.py) ------------------------------------------- */
 /* When enabled, every kernel group launched by the entry points below is bracketed by a pair of hipEvents on

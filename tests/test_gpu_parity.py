@@ -236,6 +236,31 @@ def test_pair_batch_vs_oracle(ctx, w, h, npairs):
                 assert corner_err(Hg[p], Ho[p], w, h) <= 0.05
 
 
+def test_async_solve_back_to_back_batches(ctx):
+    """RANSAC on the solve stream overlapping the next batch's detect kernels must not change any result."""
+    batches = [S.make_pair_batch(30 + i, 3, 400, 224)[0] for i in range(3)]
+    outs = []
+    ctx.set_async_solve(True)
+    try:
+        inputs = [dev(fr) for fr in batches]     # inputs must stay alive until the context has consumed them
+        torch.cuda.synchronize()
+        for d_fr in inputs:            # enqueue all three without synchronising in between
+            H = torch.zeros(3, 9, dtype=torch.float64, device="cuda")
+            st = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()   # the fills above run on torch's stream, the context on its own
+            ctx.pair_homography_batch(d_fr, 3, 0, H, st)
+            outs.append((H, st))
+        ctx.synchronize()
+    finally:
+        ctx.set_async_solve(False)
+    for fr, (H, st) in zip(batches, outs):
+        Ho, so = O.pairs_gray_batch(fr)
+        assert np.array_equal(st.cpu().numpy(), so)
+        Hg = H.cpu().numpy().reshape(-1, 3, 3)
+        ok = so == 0
+        assert np.allclose(Hg[ok], Ho[ok], rtol=1e-9, atol=1e-12)
+
+
 def test_stream_vs_oracle(ctx):
     frames, _ = S.make_stream(5, 7, 400, 224)
     n = len(frames) - 1
