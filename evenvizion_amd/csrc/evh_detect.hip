@@ -236,7 +236,7 @@ struct FastLds {
   uint32_t raw[FR_H * FR_DW];        // 40 x 36 dwords: rows y0-4.., columns x0-8..
   uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
   uint32_t lst[FT_W * FT_H / 4];     // NMS keeps at most one corner per 2x2 block
-  uint16_t queue[FS_H * FS_DW * 4];  // lifted path: pixels that pass the pre-test (score-plane byte index)
+  uint16_t queue[FS_H * FS_DW + 4];  // lifted path: quads with a pixel that passes the pre-test (index | bits << 12)
   uint16_t scored[FT_W * FT_H / 2];  // lifted path: pixels whose exact score reached T
   int lcnt, gbase, qcnt, scnt;
 };
@@ -303,32 +303,37 @@ __device__ __forceinline__ uint32_t pretest_fail2(s16x2 c, s16x2 rd, s16x2 rr, s
 }
 
 // lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
-// compass points), two pixels per packed 16-bit operation, queues the pixels that can reach T; phase B: exact
-// score of the queue with every lane busy.
+// compass points), two pixels per packed 16-bit operation; a quad with at least one passing pixel is queued
+// (quad index | pass bits << 12).  Phase B: exact score of the queued pixels, 4 lanes per queued quad.
 __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, int x0, int y0, int T) {
   const s16x2 Tp1 = {(short)(T + 1), (short)(T + 1)}, nTm1 = {(short)(-T - 1), (short)(-T - 1)};
-  // (sr, sq) walk the 34 x 34 quad grid without divisions: +256 quads = +7 rows +18 quads
+  // tiles whose whole score plane lies inside the testable range need no per-pixel range checks (wave-uniform)
+  const bool interior = (y0 - 1 >= 3) && (y0 + FT_H < L.h - 3) && (x0 - 4 >= 3) && (x0 + FT_W + 3 < L.w - 3);
+  // (sr, sq) walk the 30 x 34 quad grid without divisions: +256 quads = +7 rows +18 quads
   int sr = threadIdx.x / FS_DW, sq = threadIdx.x - sr * FS_DW;
   for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
-    const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
     S.score[i] = 0;                                             // phase B overwrites the bytes that reach T
-    if (y >= 3 && y < L.h - 3 && xq + 3 >= 3 && xq < L.w - 3) {
+    uint32_t colmask = 0xFu;
+    bool rowok = true;
+    if (!interior) {
+      const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
+      rowok = y >= 3 && y < L.h - 3;
+      const int lo = min(max(3 - xq, 0), 4), hi = max(min(L.w - 3 - xq, 4), 0);   // valid pixels j in [lo, hi)
+      colmask = (0xFu << lo) & (0xFu >> (4 - hi)) & 0xFu;
+    }
+    if (rowok && colmask) {
       const uint32_t* p = S.raw + (sr + 3) * FR_DW + sq;        // centre row, dword of x = xq-4
       const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
       const uint32_t f01 = pretest_fail2(pk_bytes(Mc, Mc, 0, 1), pk_bytes(Md, Md, 0, 1), pk_bytes(Rc, Mc, 3, 4),
                                          pk_bytes(Mu, Mu, 0, 1), pk_bytes(Mc, Lc, 1, 2), Tp1, nTm1);
       const uint32_t f23 = pretest_fail2(pk_bytes(Mc, Mc, 2, 3), pk_bytes(Md, Md, 2, 3), pk_bytes(Rc, Mc, 5, 6),
                                          pk_bytes(Mu, Mu, 2, 3), pk_bytes(Mc, Lc, 3, 4), Tp1, nTm1);
-      // bit j set <=> pixel j passes and lies in the testable column range
-      uint32_t pm = (((f01 >> 15) & 1u) | ((f01 >> 30) & 2u) | ((f23 >> 13) & 4u) | ((f23 >> 28) & 8u)) ^ 0xFu;
-      const int lo = max(3 - xq, 0), hi = min(L.w - 3 - xq, 4);   // valid pixels j in [lo, hi)
-      pm &= (0xFu << lo) & (0xFu >> (4 - hi));
-      if (pm) {
-        int slot = atomicAdd(&S.qcnt, __popc(pm));
-        const int basei = sr * FQ_PITCH + sq * 4;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (pm & (1u << j)) S.queue[slot++] = (uint16_t)(basei + j);
+      // fail bits: pixel 0 -> bit 0, pixel 1 -> bit 16, pixel 2 -> bit 2, pixel 3 -> bit 18
+      const uint32_t fb = ((f01 >> 15) | (f23 >> 13)) & 0x00050005u;
+      if (fb != 0x00050005u || false) {
+        uint32_t pm = ((fb & 1u) | ((fb >> 15) & 2u) | (fb & 4u) | ((fb >> 15) & 8u)) ^ 0xFu;
+        pm &= colmask;
+        if (pm) S.queue[atomicAdd(&S.qcnt, 1)] = (uint16_t)(i | (pm << 12));
       }
     }
     sr += 7; sq += 18;
@@ -338,10 +343,13 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
   const int nq = S.qcnt;
   const uint8_t* rawb = reinterpret_cast<const uint8_t*>(S.raw);
   uint8_t* scoreb = reinterpret_cast<uint8_t*>(S.score);
-  for (int i = threadIdx.x; i < nq; i += 256) {
-    const int pos = S.queue[i];
-    const int sr2 = pos / FQ_PITCH, sx = pos - sr2 * FQ_PITCH;
-    const uint8_t* p = rawb + (sr2 + 3) * (FR_DW * 4) + sx + 4;
+  for (int e = threadIdx.x; e < nq * 4; e += 256) {
+    const int ent = S.queue[e >> 2], j = e & 3;
+    if (!((ent >> (12 + j)) & 1)) continue;
+    const int qi = ent & 0xFFF;
+    const int sr2 = qi / FS_DW, sq2 = qi - sr2 * FS_DW;
+    const int pos = sr2 * FQ_PITCH + sq2 * 4 + j;
+    const uint8_t* p = rawb + (sr2 + 3) * (FR_DW * 4) + sq2 * 4 + j + 4;
     const int W = FR_DW * 4;
     const int v = p[0];
     i16 d[16];
