@@ -50,8 +50,8 @@ __global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int
 // K2: pyramid level l from level l-1, resize(INTER_LINEAR_EXACT): 8.8 fixed-point weights per axis,
 // out = ((c0*s00 + c1*s01)*m0 + (c0*s10 + c1*s11)*m1 + 32768) >> 16.  Tables (host-computed): per dst column
 // (xofs, xc1), per dst row (yofs, yc1); edge replication is encoded in the tables.
-// Workgroup = 128 x 16 output pixels; the source footprint (<= 160 x 22 bytes at scale 1.2) is staged in LDS with
-// coalesced dword loads, each thread then produces 2 rows x 4 pixels from LDS bytes and stores one dword per row.
+// Workgroup = 128 x 32 output pixels; the source footprint (<= 176 x 43 bytes at scale 1.2) is staged in LDS with
+// 16-byte loads, each thread then produces 4 rows x 4 pixels from LDS bytes and stores one dword per row.
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {   // a*b + c, a,b < 2^24 (half-rate VALU;
   uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;   // v_mul_lo_u32 / v_mad_u64_u32 are far slower)
 }
@@ -59,38 +59,42 @@ __device__ __forceinline__ int mad24s(int a, int b, int c) {   // signed a*b + c
   int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
 #define PD_W 128
-#define PD_H 16
-#define PD_SW 176   // staged source row bytes (multiple of 16, >= 1.2*128 + 2 + 15)
-#define PD_SH 24    // staged source rows (>= 1.2*16 + 3)
-// INTER_LINEAR_EXACT sampling position of destination index v: left/top tap and the 8.8 weight of the right/bottom
-// tap (the same f64 operations, in the same order, as the host reference table in evh_api.hip; samples that fall
-// off either end put the full weight on the edge sample).
-__device__ __forceinline__ void lin_coef(int v, double scale, int ssize, int& ofs, uint32_t& c1) {
-  const double fval = scale * ((double)v + 0.5) - 0.5;
-  const int ival = (int)__builtin_floor(fval);
-  if (ival >= 0 && ssize > 1) {
-    if (ival < ssize - 1) { ofs = ival; c1 = (uint32_t)(int)__builtin_rint((fval - (double)ival) * 256.0); }
-    else { ofs = ssize - 2; c1 = 256u; }
-  } else { ofs = 0; c1 = 0u; }
+#define PD_H 32
+#define PD_SW 192   // staged source row bytes (multiple of 16, >= 1.2*128 + 4 + 15 of slack and alignment)
+#define PD_SH 44    // staged source rows (>= 1.2*32 + 5)
+// conservative integer estimate of floor(scale*(v+0.5)-0.5) with scale ~ ssize/dsize (only used to bound the source
+// footprint of a tile; the exact taps come from the host-built tables)
+__device__ __forceinline__ int lin_ofs_estimate(int v, int ssize, int dsize) {
+  return ((2 * v + 1) * ssize - dsize) / (2 * dsize);
 }
 
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t src_off,
                                                   int src_stride, int sw, int sh, int64_t dst_off, int dst_stride, int dw,
-                                                  int dh, int tiles_x, double scale_x, double scale_y) {
+                                                  int dh, int tiles_x, const int* __restrict__ xofs,
+                                                  const int* __restrict__ xc1, const int* __restrict__ yofs,
+                                                  const int* __restrict__ yc1) {
   __shared__ uint32_t tile32[PD_SH * PD_SW / 4];
+  __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
   const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
   const int f = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int x0 = tx * PD_W, y0 = ty * PD_H;
   const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PD_H, dh) - 1;
-  int ox0, ox1, oy0, oy1; uint32_t cdummy;
-  lin_coef(x0, scale_x, sw, ox0, cdummy); lin_coef(x1, scale_x, sw, ox1, cdummy);
-  lin_coef(y0, scale_y, sh, oy0, cdummy); lin_coef(y1, scale_y, sh, oy1, cdummy);
-  const int sx0 = ox0 & ~15, sy0 = oy0;
-  const int ncol16 = (ox1 + 1 - sx0) / 16 + 1, nrow = oy1 + 2 - sy0;   // <= PD_SW/16 = 11, <= PD_SH
+  // source footprint, bounded without touching memory (one pixel of slack on each side)
+  const int sx0 = max(lin_ofs_estimate(x0, sw, dw) - 1, 0) & ~15, sy0 = max(lin_ofs_estimate(y0, sh, dh) - 1, 0);
+  const int ex = min(lin_ofs_estimate(x1, sw, dw) + 2, sw - 1), ey = min(lin_ofs_estimate(y1, sh, dh) + 2, sh - 1);
+  const int ncol16 = (ex - sx0) / 16 + 1, nrow = ey - sy0 + 1;     // <= PD_SW/16 = 11, <= PD_SH
   uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;   // wave-uniform 64-bit bases; per-lane offsets stay 32-bit
   const uint8_t* simg = base + src_off + sx0;
   uint8_t* dimg = base + dst_off;
+  // exact taps of this tile's 128 columns / 16 rows from the host tables (independent of the staging loads)
+  if (threadIdx.x < PD_W) {
+    const int xi = min(x0 + (int)threadIdx.x, dw - 1);
+    xo_s[threadIdx.x] = xofs[xi] - sx0; xc_s[threadIdx.x] = xc1[xi];
+  } else if (threadIdx.x < PD_W + PD_H) {
+    const int r = threadIdx.x - PD_W, yi = min(y0 + r, dh - 1);
+    yo_s[r] = yofs[yi] - sy0; yc_s[r] = yc1[yi];
+  }
   {
     // 16-byte loads: a thread moves one (row, 16-byte column) cell; 16 threads cover a source row of <= 176 bytes
     const int c16 = threadIdx.x & 15;
@@ -99,31 +103,20 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
       const int stride16 = src_stride >> 4;
       for (int r = threadIdx.x >> 4; r < nrow; r += 16)
         *reinterpret_cast<uint4*>(&tile32[r * (PD_SW / 4) + c16 * 4]) =
-            col[mad24((uint32_t)min(sy0 + r, sh - 1), (uint32_t)stride16, 0u)];
+            col[mad24((uint32_t)(sy0 + r), (uint32_t)stride16, 0u)];
     }
   }
-  // per-tile coefficient tables: 128 column taps by threads 0..127, 16 row taps by threads 128..143 (f64 once per
-  // output column / row instead of once per thread)
-  __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
-  if (threadIdx.x < PD_W) {
-    int o; uint32_t c; lin_coef(min(x0 + (int)threadIdx.x, dw - 1), scale_x, sw, o, c);
-    xo_s[threadIdx.x] = o - sx0; xc_s[threadIdx.x] = (int)c;
-  } else if (threadIdx.x < PD_W + PD_H) {
-    const int r = threadIdx.x - PD_W;
-    int o; uint32_t c; lin_coef(min(y0 + r, dh - 1), scale_y, sh, o, c);
-    yo_s[r] = o - sy0; yc_s[r] = (int)c;
-  }
   __syncthreads();
-  const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;     // 32 quads across, 8 row pairs down
+  const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;     // 32 quads across, 8 groups of PD_H/8 rows down
   const int x = x0 + qx * 4;
   if (x >= dw) return;
 #pragma unroll
-  for (int rr = 0; rr < 2; rr++) {
-    const int y = y0 + qy * 2 + rr;
+  for (int rr = 0; rr < PD_H / 8; rr++) {
+    const int y = y0 + qy * (PD_H / 8) + rr;
     if (y >= dh) break;
-    const uint8_t* r0 = tile + yo_s[qy * 2 + rr] * PD_SW;
+    const uint8_t* r0 = tile + yo_s[qy * (PD_H / 8) + rr] * PD_SW;
     const uint8_t* r1 = r0 + PD_SW;
-    const int m1 = yc_s[qy * 2 + rr];
+    const int m1 = yc_s[qy * (PD_H / 8) + rr];
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -934,10 +927,10 @@ int evh_launch_pyramid(evh_ctx* c, int nframes) {
     const EvhLevel& S = c->g.lv[l - 1];
     const EvhLevel& D = c->g.lv[l];
     const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;
-    const double scale_x = 1.0 / ((double)D.w / S.w), scale_y = 1.0 / ((double)D.h / S.h);   // as cv::resize derives them
+    const int* t = c->d_tabs + D.tab_off;   // xofs | xc1 | yofs | yc1 (linear_exact_tab in evh_api.hip)
     hipLaunchKernelGGL(k_pyr_down, dim3(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
-                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x, scale_x,
-                       scale_y);
+                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x, t, t + D.w,
+                       t + 2 * D.w, t + 2 * D.w + D.h);
     EVH_HIP(c, hipGetLastError());
   }
   return EVH_SUCCESS;

@@ -189,6 +189,9 @@ int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs) {
 int evh_launch_filter(evh_ctx* c, const EvhFilterArgs& A, int npairs) {
   if (npairs <= 0) return EVH_SUCCESS;
   size_t lds = sizeof(int) * 5 * (size_t)A.kcap;
+  if (lds > 48 * 1024)   // large key-point budgets (N = 4000 -> ~105 KB): opt in to more dynamic LDS than the default
+    EVH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
   hipLaunchKernelGGL(k_filter, dim3(npairs), dim3(256), lds, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;

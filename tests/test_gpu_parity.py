@@ -261,6 +261,33 @@ def test_async_solve_back_to_back_batches(ctx):
         assert np.allclose(Hg[ok], Ho[ok], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("w,h,nfeat", [(1280, 720, 2000), (1920, 1080, 2000), (3840, 2160, 4000)])
+def test_other_baseline_configs_one_pair(w, h, nfeat):
+    """BASELINE.json configs 2-4 geometry (ORB 2000 @720p/1080p, ORB 4000 @4K): one pair each, full path vs oracle."""
+    from evenvizion_amd._lib import Context
+    prev, cur, Ht = S.make_pair(4000 + w, w, h)
+    c = Context(device=0, max_w=w, max_h=h, max_features=nfeat, max_frames=2)
+    try:
+        fr = dev(np.stack([prev, cur]))
+        c.orb_detect_batch(fr, nfeatures=nfeat)
+        for f, img in enumerate((prev, cur)):
+            g = c.orb_download(f)
+            o = O.orb_detect(img, nfeatures=nfeat)
+            assert len(g["xy"]) == len(o["xy"]) > nfeat // 2
+            assert np.array_equal(g["octave"], o["octave"]) and np.array_equal(g["lx"], o["lx"]) and np.array_equal(g["ly"], o["ly"])
+            assert np.array_equal(g["desc"], o["desc"])
+        H = torch.zeros(1, 9, dtype=torch.float64, device="cuda"); st = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(fr, 1, 0, H, st, nfeatures=nfeat)
+        c.synchronize()
+        so, Ho = O.pair_gray(cur, prev, nfeatures=nfeat)
+        assert st.cpu().tolist() == [so]
+        if so == 0:
+            assert np.allclose(H.cpu().numpy().reshape(3, 3), Ho, rtol=1e-9, atol=1e-12)
+            assert corner_err(Ho, Ht, w, h) < 0.03 * w
+    finally:
+        c.close()
+
+
 def test_stream_vs_oracle(ctx):
     frames, _ = S.make_stream(5, 7, 400, 224)
     n = len(frames) - 1
