@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=500)
     ap.add_argument("--channels", type=int, default=3, choices=[1, 3])
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--contexts", type=int, default=1, help="independent contexts/streams the steps alternate over")
     args = ap.parse_args()
 
     import torch
@@ -101,36 +102,43 @@ def main():
     frames = uniq.repeat((reps,) + (1,) * (uniq.dim() - 1))[:2 * B].contiguous()   # physical copies in HBM
     del host, uniq
 
-    stream = torch.cuda.Stream(device=dev)
-    ctx = Context(device=local_rank, max_w=w, max_h=h, max_features=args.nfeatures, max_frames=2 * B,
-                  stream=stream.cuda_stream)
+    # Steps alternate over `--contexts` independent contexts, each with its own HIP stream (+ its solve stream):
+    # consecutive steps have no data dependence, so their kernels overlap and fill each other's launch tails.
+    NCTX = max(1, args.contexts)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NCTX)]
+    ctxs = [Context(device=local_rank, max_w=w, max_h=h, max_features=args.nfeatures, max_frames=2 * B,
+                    stream=streams[i].cuda_stream) for i in range(NCTX)]
+    stream, ctx = streams[0], ctxs[0]
     # The RANSAC kernels of a step run on the context's solve stream and overlap the next step's detect kernels;
     # results are double-buffered so that a step never overwrites what the previous step's gather still reads.
-    ctx.set_async_solve(True)
-    Hs = [torch.zeros(B, 9, dtype=torch.float64, device=dev) for _ in range(2)]
-    sts = [torch.full((B,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
+    for c_ in ctxs:
+        c_.set_async_solve(True)
+    NBUF = 2 * NCTX
+    Hs = [torch.zeros(B, 9, dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    sts = [torch.full((B,), -1, dtype=torch.int32, device=dev) for _ in range(NBUF)]
     gathered = torch.zeros(world * B, 9, dtype=torch.float64, device=dev) if use_dist else None
     gstream = torch.cuda.Stream(device=dev) if use_dist else None
-    gdone = [None, None]
+    gdone = [None] * NBUF
     counter = [0]
 
     def step():
-        k = counter[0] & 1
+        k = counter[0] % NBUF
+        cx, sx = ctxs[counter[0] % NCTX], streams[counter[0] % NCTX]
         counter[0] += 1
         if use_dist and gdone[k] is not None:
-            stream.wait_event(gdone[k])           # the gather that read this buffer two steps ago has finished
-        ctx.pair_homography_batch(frames, B, MODE_INDEPENDENT_PAIRS, Hs[k], sts[k], nfeatures=args.nfeatures)
+            sx.wait_event(gdone[k])               # the gather that read this buffer NBUF steps ago has finished
+        cx.pair_homography_batch(frames, B, MODE_INDEPENDENT_PAIRS, Hs[k], sts[k], nfeatures=args.nfeatures)
         if use_dist:
             # RCCL over xGMI: gather the per-pair H records of THIS step on a side stream behind the solve
-            ctx.solve_wait(gstream.cuda_stream)
+            cx.solve_wait(gstream.cuda_stream)
             with torch.cuda.stream(gstream):
                 dist.all_gather_into_tensor(gathered, Hs[k])
                 ev = torch.cuda.Event()
                 ev.record(gstream)
             gdone[k] = ev
 
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
+    if True:
+        for _ in range(max(args.warmup, NCTX)):
             step()
         torch.cuda.synchronize(dev)
         if saved_stdout is not None:
@@ -140,8 +148,9 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
             saved_stdout = None
-        ctx.profile_read()            # drop warm-up spans
-        ctx.profile_enable(True)
+        for c_ in ctxs:
+            c_.profile_read()         # drop warm-up spans
+            c_.profile_enable(True)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -153,15 +162,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
-    ctx.profile_enable(False)
-    stages = ctx.profile_read()
+    stages = {}
+    for c_ in ctxs:
+        c_.profile_enable(False)
+        for name, (cnt_, ms_) in c_.profile_read().items():
+            a_, b_ = stages.get(name, (0, 0.0))
+            stages[name] = (a_ + cnt_, b_ + ms_)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ctx.synchronize()
-    last = (counter[0] - 1) & 1
+    for c_ in ctxs:
+        c_.synchronize()
+    last = (counter[0] - 1) % NBUF
     H, status = Hs[last], sts[last]
     st = status.cpu().numpy()
     ok_frac = float((st == 0).mean())
@@ -223,13 +237,14 @@ def main():
             "config": {"workload": "synthetic %dx%d %s pair batch, %d independent pairs/step/GPU, ORB %d kp, "
                                    "RANSAC max 2000 conf 0.995 (BASELINE.json configs[1])"
                                    % (w, h, "BGR" if args.channels == 3 else "gray", B, args.nfeatures),
-                       "pairs_per_step_per_gpu": B, "unique_pairs": U, "parallelism": "pairs sharded, dp%d" % world,
+                       "pairs_per_step_per_gpu": B, "unique_pairs": U, "parallelism": "pairs sharded, dp%d" % world, "contexts_per_gpu": NCTX,
                        "pairs_ok_fraction": ok_frac,
                        "arithmetic": "u8/i32 pixels+descriptors, f32 Harris+reprojection, f64 DLT+LM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
     if use_dist:
         dist.destroy_process_group()
 
