@@ -33,6 +33,7 @@ SIGNATURES = {
     "evh_profile_read": (_i, [_vp, _vp, _vp]),
     "evh_profile_stage_name": (C.c_char_p, [_i]),
     "evh_resize_area_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp, _i, _i, _i64, _i64]),
+    "evh_fixed_plane_field": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
     "evh_set_fast_lift": (_i, [_vp, _i]),
     "evh_orb_count": (_i, [_vp, _i]),
@@ -157,6 +158,14 @@ class Context:
 
     def set_fast_lift(self, on=True):
         self._check(self.lib.evh_set_fast_lift(self.h, int(bool(on))))
+
+    def fixed_plane_max(self, Hsup, w, h, field=None):
+        """Hsup f64[n,3,3] -> f64[n]: max fixed-plane coordinate over the w x h grid of each matrix."""
+        Hs = np.ascontiguousarray(Hsup, np.float64).reshape(-1, 9)
+        out = np.zeros(len(Hs), np.float64)
+        self._check(self.lib.evh_fixed_plane_field(self.h, _hp(Hs), len(Hs), int(w), int(h),
+                                                   field.data_ptr() if field is not None else None, _hp(out)))
+        return out
 
     # ---- K1..K6 ----
     def orb_detect_batch(self, frames, nfeatures=500):

@@ -352,6 +352,31 @@ int evh_resize_area_u8(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int s
                                 dst_img_stride);
 }
 
+int evh_fixed_plane_field(evh_ctx* c, const double* h_Hsup, int n, int w, int h, double* d_field, double* h_max) {
+  if (!c || !h_Hsup || !h_max || n < 1 || w < 1 || h < 1) return evh_fail(c, EVH_ERR_INVALID, "evh_fixed_plane_field: bad argument");
+  if (n > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "evh_fixed_plane_field: at most 65535 matrices per call");
+  double* d_H = nullptr; unsigned long long* d_max = nullptr;
+  EVH_HIP(c, hipMalloc(&d_H, sizeof(double) * 9 * (size_t)n));
+  hipError_t e = hipMalloc(&d_max, sizeof(unsigned long long) * (size_t)n);
+  if (e != hipSuccess) { (void)hipFree(d_H); return evh_fail(c, EVH_ERR_HIP, "hipMalloc failed"); }
+  std::vector<unsigned long long> keys(n);
+  int rc = EVH_SUCCESS;
+  e = hipMemcpyAsync(d_H, h_Hsup, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = evh_launch_fixed_plane(c, d_H, n, w, h, d_field, d_max);
+  if (e == hipSuccess && rc == EVH_SUCCESS)
+    e = hipMemcpyAsync(keys.data(), d_max, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_H); (void)hipFree(d_max);
+  if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("evh_fixed_plane_field: ") + hipGetErrorString(e));
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    unsigned long long b = keys[i];
+    b = (b >> 63) ? (b & 0x7FFFFFFFFFFFFFFFull) : ~b;
+    memcpy(&h_max[i], &b, sizeof(double));
+  }
+  return EVH_SUCCESS;
+}
+
 int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
                          int64_t row_stride, int64_t frame_stride, int nfeatures) {
   if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, "evh_orb_detect_batch: NULL argument");

@@ -57,6 +57,33 @@ __global__ void k_resize_area_int(const uint8_t* __restrict__ src, int cn, int64
   dst[(int64_t)img * dst_img_stride + (int64_t)dy * dst_stride + e] = (uint8_t)min(max(v, 0), 255);
 }
 
+// N3: fixed-plane coordinate field of processing_visualization.py:407-408 -- every pixel (x, y) of
+// the resized frame mapped through the frame's superposed H -- and its maximum coordinate (the value
+// heatmap_video_processing returns and evenvizion_component.py writes to metrics_file.txt).
+__global__ __launch_bounds__(256) void k_fixed_plane(const double* __restrict__ Hs, int w, int h,
+                                                     double* __restrict__ field, unsigned long long* __restrict__ out_max) {
+  const int f = blockIdx.y;
+  const double* H = Hs + 9 * f;
+  const double h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6], h7 = H[7], h8 = H[8];
+  double m = -INFINITY;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    const double dx = (double)x, dy = (double)y;
+    const double d = (h6 * dx + h7 * dy) + h8;
+    const double u = ((h0 * dx + h1 * dy) + h2) / d;
+    const double v = ((h3 * dx + h4 * dy) + h5) / d;
+    if (field) { field[((int64_t)f * w * h + i) * 2] = u; field[((int64_t)f * w * h + i) * 2 + 1] = v; }
+    m = fmax(m, fmax(u, v));
+  }
+  for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s));
+  if ((threadIdx.x & 63) == 0 && m > -INFINITY) {
+    // order-preserving key of a double so that an integer atomicMax gives the floating-point maximum
+    unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    atomicMax(&out_max[f], b);
+  }
+}
+
 struct HostTab { std::vector<int> start, cnt, si; std::vector<float> al; };
 
 void build_area_tab(int ssize, int dsize, double scale, HostTab& t) {
@@ -125,5 +152,13 @@ int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, i
   (void)hipStreamSynchronize(c->stream);  // the pageable upload and the table lifetime both end here
   (void)hipFree(d_blob);
   if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("k_resize_area: ") + hipGetErrorString(e));
+  return EVH_SUCCESS;
+}
+
+int evh_launch_fixed_plane(evh_ctx* c, const double* d_H, int n, int w, int h, double* d_field, unsigned long long* d_max) {
+  EVH_HIP(c, hipMemsetAsync(d_max, 0, sizeof(unsigned long long) * (size_t)n, c->stream));
+  const int blocks = std::min((w * h + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_fixed_plane, dim3(blocks, n), dim3(256), 0, c->stream, d_H, w, h, d_field, d_max);
+  EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }

@@ -86,6 +86,13 @@ int evh_resize_area_u8(evh_ctx* ctx, const uint8_t* d_src, int nimg, int sw, int
                        int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
                        int64_t dst_img_stride);
 
+/* ---- N3: fixed-plane coordinate field of the heat-map (processing_visualization.py:407-408,419) ------- */
+/* For each of n superposed matrices h_Hsup f64[n,9]: (u,v) = H.(x,y,1) for every pixel of a w x h grid (what
+ * np.apply_along_axis(homography_transformation, 2, template, H) computes) and max over the grid of max(u,v) --
+ * the per-frame value whose maximum over the video is written to metrics_file.txt.  d_field (device,
+ * f64[n,h,w,2], may be NULL) receives the field; h_max f64[n] the maxima.  Synchronises.                     */
+int evh_fixed_plane_field(evh_ctx* ctx, const double* h_Hsup, int n, int w, int h, double* d_field, double* h_max);
+
 /* ---- K1..K6: ORB detectAndCompute on a batch of frames ------------------------------------------------------- */
 /* channels: 1 (gray) or 3 (BGR, converted like cvtColor(BGR2GRAY)).  Results stay resident in the context
  * (frame slots 0..nframes-1) until the next call.                                                              */

@@ -366,3 +366,31 @@ def test_python_api_mirror_vs_oracle():
     for k in range(2, 7):
         assert np.allclose(np.array(d[k]["H"]), Hs2[k - 2], rtol=1e-9, atol=1e-12)
     runtime.reset()
+
+
+def test_heatmap_extent_reproduces_reference_metrics_file():
+    """N3: the GPU coordinate field reproduces the reference's committed metrics_file.txt bit for bit
+    (Maximum movement during the entire video: 863.0428982580879) from the committed H JSON."""
+    import os
+    from evenvizion_amd import heatmap, runtime
+    from evenvizion_amd.processing import utils
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    hd, ri = utils.read_homography_dict(os.path.join(gold, "ref_dict_with_homography_matrix.json"))
+    sup = utils.superposition_dict(hd)
+    want = float(open(os.path.join(gold, "ref_metrics_file.txt")).read().split(":")[1])
+    runtime.reset()
+    assert heatmap.max_movement(sup, ri) == want == 863.0428982580879
+    keys, m = heatmap.frame_maxima(sup, ri)
+    assert keys[0] == 1 and m[0] == 399.0          # frame 1 = identity: max(x) over the 400 x 224 grid
+    ys, xs = np.mgrid[0:ri["h"], 0:ri["w"]].astype(np.float64)
+    Hk = np.asarray(sup[keys[60]], np.float64)
+    d = Hk[2, 0] * xs + Hk[2, 1] * ys + Hk[2, 2]
+    u = (Hk[0, 0] * xs + Hk[0, 1] * ys + Hk[0, 2]) / d; v = (Hk[1, 0] * xs + Hk[1, 1] * ys + Hk[1, 2]) / d
+    assert m[60] == max(u.max(), v.max())
+    import torch
+    field = torch.zeros(1, ri["h"], ri["w"], 2, dtype=torch.float64, device="cuda")
+    ctx = runtime.get_context(400, 224)
+    ctx.fixed_plane_max(Hk[None], ri["w"], ri["h"], field=field)
+    got = field.cpu().numpy()[0]
+    assert np.array_equal(got[..., 0], u) and np.array_equal(got[..., 1], v)
+    runtime.reset()
