@@ -80,7 +80,6 @@ struct evh_ctx {
   double* d_lm = nullptr;         // [max_pairs][kcap][4] LM per-point temporaries
   float* d_crow = nullptr;        // [max_pairs][kcap][4] compacted inlier rows
   int* d_info = nullptr;          // [max_pairs][8]
-  double* d_Hsup = nullptr;       // [9] stream state carried between batches (unused in round 1)
   double* d_small = nullptr;      // small staging area for single-problem entries (H, counts)
   size_t bytes_allocated = 0;
   std::string err;
