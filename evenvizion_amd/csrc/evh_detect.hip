@@ -6,21 +6,9 @@
 
 namespace {
 
-// ------------------------------------------------------------------------------------------------------------
-// K1: BGR -> gray (Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14) or gray copy, into pyramid level 0.
-// One thread = 4 output pixels: three aligned dword loads (12 BGR bytes) -> one dword store; grid.y = frame.
-__global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int64_t row_stride, int64_t frame_stride,
-                              uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int w, int h, int dst_stride,
-                              int aligned4) {
-  const int f = blockIdx.y;
-  const int qpr = (w + 3) >> 2;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= qpr * h) return;
-  const int y = q / qpr, x = (q - y * qpr) * 4;
-  const uint8_t* s = src + (int64_t)f * frame_stride + (int64_t)y * row_stride + (int64_t)x * channels;
-  uint8_t* d = pyr + (int64_t)f * pyr_frame_bytes + (int64_t)y * dst_stride + x;
+// 4 gray pixels (n < 4 at the right edge) from `s`: Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14, or a plain copy
+__device__ __forceinline__ uint32_t gray_quad(const uint8_t* __restrict__ s, int channels, int n, int aligned4) {
   uint32_t out = 0;
-  const int n = min(4, w - x);
   if (aligned4 && n == 4) {
     if (channels == 1) out = *reinterpret_cast<const uint32_t*>(s);
     else {
@@ -43,6 +31,23 @@ __global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int
       out |= ((b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14) << (8 * i);
     }
   }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1: BGR -> gray (Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14) or gray copy, into pyramid level 0.
+// One thread = 4 output pixels: three aligned dword loads (12 BGR bytes) -> one dword store; grid.y = frame.
+__global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int64_t row_stride, int64_t frame_stride,
+                              uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int w, int h, int dst_stride,
+                              int aligned4) {
+  const int f = blockIdx.y;
+  const int qpr = (w + 3) >> 2;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= qpr * h) return;
+  const int y = q / qpr, x = (q - y * qpr) * 4;
+  const uint8_t* s = src + (int64_t)f * frame_stride + (int64_t)y * row_stride + (int64_t)x * channels;
+  uint8_t* d = pyr + (int64_t)f * pyr_frame_bytes + (int64_t)y * dst_stride + x;
+  const uint32_t out = gray_quad(s, channels, min(4, w - x), aligned4);
   *reinterpret_cast<uint32_t*>(d) = out;  // rows are 64-byte aligned and padded, a full dword is always in range
 }
 
@@ -122,6 +127,77 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
     for (int i = 0; i < 4; i++) {
       const int o = xo_s[qx * 4 + i], c1 = xc_s[qx * 4 + i];
       // c0*a + c1*b with c0 = 256 - c1  ==  256*a + c1*(b - a); likewise for the vertical pass
+      const int a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
+      const int h0 = mad24s(c1, b0 - a0, a0 << 8);
+      const int h1 = mad24s(c1, b1 - a1, a1 << 8);
+      out |= ((uint32_t)(mad24s(m1, h1 - h0, (h0 << 8) + 32768)) >> 16) << (8 * i);
+    }
+    reinterpret_cast<uint32_t*>(dimg)[mad24((uint32_t)y, (uint32_t)(dst_stride >> 2), (uint32_t)(x >> 2))] = out;
+  }
+}
+
+// K1+K2 fused for level 1: a workgroup owns one 128 x 32 tile of level 1. It converts the level-0 footprint of that
+// tile straight from the BGR/gray input into LDS (gray never re-read from HBM), writes the level-0 pixels it OWNS
+// (columns [xofs[x0] & ~3, xofs[x0 + 128] & ~3), rows [yofs[y0], yofs[y0 + 32]); the monotone tap tables make these
+// ranges a partition of level 0) and then produces its level-1 tile from LDS exactly as k_pyr_down does.
+#define GP_SW 176   // LDS gray row bytes (>= 1.21*128 + 7, multiple of 4)
+#define GP_SH 44    // LDS gray rows      (>= 1.21*32 + 3)
+__global__ __launch_bounds__(256) void k_gray_pyr1(const uint8_t* __restrict__ src, int channels, int64_t row_stride,
+                                                   int64_t frame_stride, int aligned4, uint8_t* __restrict__ pyr,
+                                                   int64_t pyr_frame_bytes, int s_stride, int sw, int sh, int64_t dst_off,
+                                                   int dst_stride, int dw, int dh, int tiles_x, int tiles_y,
+                                                   const int* __restrict__ xofs, const int* __restrict__ xc1,
+                                                   const int* __restrict__ yofs, const int* __restrict__ yc1) {
+  __shared__ uint32_t tile32[GP_SH * GP_SW / 4];
+  __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
+  const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
+  const int f = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int x0 = tx * PD_W, y0 = ty * PD_H;
+  const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PD_H, dh) - 1;
+  const int rx0 = xofs[x0] & ~3, ry0 = yofs[y0];
+  const int own_x1 = (tx == tiles_x - 1) ? ((sw + 3) & ~3) : (xofs[x0 + PD_W] & ~3);
+  const int own_y1 = (ty == tiles_y - 1) ? sh : yofs[y0 + PD_H];
+  const int rx1 = max(own_x1, min(xofs[x1] + 2, sw)), ry1 = max(own_y1, min(yofs[y1] + 2, sh));   // exclusive
+  const int nqx = (rx1 - rx0 + 3) >> 2, nr = ry1 - ry0;                                             // <= 44, <= 44
+  if (threadIdx.x < PD_W) {
+    const int xi = min(x0 + (int)threadIdx.x, dw - 1);
+    xo_s[threadIdx.x] = xofs[xi] - rx0; xc_s[threadIdx.x] = xc1[xi];
+  } else if (threadIdx.x < PD_W + PD_H) {
+    const int r = threadIdx.x - PD_W, yi = min(y0 + r, dh - 1);
+    yo_s[r] = yofs[yi] - ry0; yc_s[r] = yc1[yi];
+  }
+  const uint8_t* sframe = src + (int64_t)f * frame_stride;
+  uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;
+  const float inv = 1.0f / (float)nqx;
+  for (int q = threadIdx.x; q < nqx * nr; q += 256) {
+    const int r = (int)(((float)q + 0.5f) * inv);     // exact: q + 0.5 is at least 0.5 away from a multiple of nqx
+    const int qx = q - (int)mad24((uint32_t)r, (uint32_t)nqx, 0u);
+    const int x = rx0 + 4 * qx, y = ry0 + r;
+    if (x >= sw) continue;                             // padding quad: never read by a tap, never stored
+    // per-lane offsets stay 32-bit (frames are < 4096 x 4096 x 3 bytes)
+    const uint32_t so = mad24((uint32_t)y, (uint32_t)row_stride, channels == 1 ? (uint32_t)x : 3u * (uint32_t)x);
+    const uint32_t g = gray_quad(sframe + so, channels, min(4, sw - x), aligned4);
+    tile32[r * (GP_SW / 4) + qx] = g;
+    if (x < own_x1 && y < own_y1)
+      *reinterpret_cast<uint32_t*>(base + mad24((uint32_t)y, (uint32_t)s_stride, (uint32_t)x)) = g;
+  }
+  __syncthreads();
+  uint8_t* dimg = base + dst_off;
+  const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;
+  const int x = x0 + qx * 4;
+  if (x >= dw) return;
+#pragma unroll
+  for (int rr = 0; rr < PD_H / 8; rr++) {
+    const int y = y0 + qy * (PD_H / 8) + rr;
+    if (y >= dh) break;
+    const uint8_t* r0 = tile + yo_s[qy * (PD_H / 8) + rr] * GP_SW;
+    const uint8_t* r1 = r0 + GP_SW;
+    const int m1 = yc_s[qy * (PD_H / 8) + rr];
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int o = xo_s[qx * 4 + i], c1 = xc_s[qx * 4 + i];
       const int a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
       const int h0 = mad24s(c1, b0 - a0, a0 << 8);
       const int h1 = mad24s(c1, b1 - a1, a1 << 8);
@@ -913,17 +989,29 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
 int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int channels, int64_t row_stride,
                            int64_t frame_stride) {
   const EvhLevel& L = c->g.lv[0];
-  int quads = ((L.w + 3) / 4) * L.h;
-  dim3 grid((quads + 255) / 256, nframes);
+  const EvhLevel& D = c->g.lv[1];
   const int aligned4 = (((uintptr_t)d_frames | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 3) == 0;
-  hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, c->stream, d_frames, channels, row_stride, frame_stride, c->d_pyr,
-                     c->g.pyr_frame_bytes, L.w, L.h, L.stride, aligned4);
+  // level 1 is produced by the same launch whenever its scale keeps the footprint of a tile inside the LDS tile
+  c->level1_fused = (int64_t)L.w * 100 <= (int64_t)D.w * 121 && (int64_t)L.h * 100 <= (int64_t)D.h * 121 && D.w >= 2 &&
+                    D.h >= 2 && row_stride < (1 << 24);
+  if (c->level1_fused) {
+    const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;
+    const int* t = c->d_tabs + D.tab_off;
+    hipLaunchKernelGGL(k_gray_pyr1, dim3(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, d_frames, channels,
+                       row_stride, frame_stride, aligned4, c->d_pyr, c->g.pyr_frame_bytes, L.stride, L.w, L.h, D.off,
+                       D.stride, D.w, D.h, tiles_x, tiles_y, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
+  } else {
+    int quads = ((L.w + 3) / 4) * L.h;
+    dim3 grid((quads + 255) / 256, nframes);
+    hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, c->stream, d_frames, channels, row_stride, frame_stride,
+                       c->d_pyr, c->g.pyr_frame_bytes, L.w, L.h, L.stride, aligned4);
+  }
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
 
 int evh_launch_pyramid(evh_ctx* c, int nframes) {
-  for (int l = 1; l < EVH_NLEVELS; l++) {
+  for (int l = c->level1_fused ? 2 : 1; l < EVH_NLEVELS; l++) {
     const EvhLevel& S = c->g.lv[l - 1];
     const EvhLevel& D = c->g.lv[l];
     const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;

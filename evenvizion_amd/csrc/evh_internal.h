@@ -47,6 +47,7 @@ struct evh_ctx {
   int kcap = 0;  // keypoint rows per frame slot
   EvhGeom g{};
   bool geom_valid = false;
+  bool level1_fused = false;   // set by evh_launch_gray_level0: level 1 was produced together with level 0
   int nframes_resident = 0;
   // device buffers
   uint8_t* d_pyr = nullptr;       // [max_frames][pyr_frame_bytes]
