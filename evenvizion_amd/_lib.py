@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevhip.so")
+# EVHIP_LIBRARY selects another build of the same C ABI (A/B measurements of two kernel variants on one box)
+LIB_PATH = os.environ.get("EVHIP_LIBRARY") or os.path.join(_HERE, "libevhip.so")
 
 EVH_SUCCESS = 0
 PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_FEW_MATCHES, PAIR_NO_PROVISIONAL_H, PAIR_LOW_INLIER_RATIO, PAIR_NO_FINAL_H, \
