@@ -352,30 +352,35 @@ __device__ __forceinline__ void fast_dense_scores(FastLds& S, const EvhLevel& L,
   }
 }
 
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-// {0, byte selB, 0, byte selA} of the 8-byte window {hi:lo} -> two zero-extended 16-bit lanes (one v_perm_b32)
-__device__ __forceinline__ s16x2 pk_bytes(uint32_t hi, uint32_t lo, uint32_t selA, uint32_t selB) {
-  uint32_t r = __builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (selB << 16) | selA);
-  return __builtin_bit_cast(s16x2, r);
+// 4-point pre-test, byte-parallel (4 pixels per dword).  Bit 7 of each result byte is set where the pixel PASSES:
+// centre - ring > T for two adjacent compass points (D), or ring - centre > T for two adjacent ones (B).
+// Adjacent pairs of a 4-cycle: (D0&D4)|(D4&D8)|(D8&D12)|(D12&D0) == (D0|D8)&(D4|D12).  K4 = (T+1) * 0x01010101, T+1 <= 127.
+// swar_ge: bit 7 of every byte = (a >= b), from the 7-bit difference t = (a|H) - (b&~H) which never borrows.
+__device__ __forceinline__ uint32_t swar_ge(uint32_t aH, uint32_t a, uint32_t b, uint32_t bL) {
+  const uint32_t t = aH - bL;
+  return (a & ~b) | (~(a ^ b) & t);
 }
-__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
-// sign bits (0x8000 per lane) set where the 4-point pre-test FAILS at threshold T for a pixel pair:
-// pass <=> two adjacent compass differences both > T, or both < -T
-__device__ __forceinline__ uint32_t pretest_fail2(s16x2 c, s16x2 rd, s16x2 rr, s16x2 ru, s16x2 rl, s16x2 Tp1, s16x2 nTm1) {
-  const s16x2 d0 = c - rd, d4 = c - rr, d8 = c - ru, d12 = c - rl;
-  const s16x2 lo = pmax(pmax(pmin(d0, d4), pmin(d4, d8)), pmax(pmin(d8, d12), pmin(d12, d0)));
-  const s16x2 hi = pmin(pmin(pmax(d0, d4), pmax(d4, d8)), pmin(pmax(d8, d12), pmax(d12, d0)));
-  const s16x2 t1 = lo - Tp1;      // >= 0  <=>  lo > T
-  const s16x2 t2 = nTm1 - hi;     // >= 0  <=>  hi < -T
-  return __builtin_bit_cast(uint32_t, t1) & __builtin_bit_cast(uint32_t, t2) & 0x80008000u;
+__device__ __forceinline__ uint32_t pretest_pass4(uint32_t c, uint32_t rd, uint32_t rr, uint32_t ru, uint32_t rl, uint32_t K4) {
+  const uint32_t H = 0x80808080u, Lm = 0x7F7F7F7Fu;
+  const uint32_t t = (c | H) - K4;     // 128 + (c & 127) - K per byte
+  const uint32_t cl = t & (c | Lm);    // c - K where c >= K
+  const uint32_t vD = c | t;           // bit 7: c >= K
+  const uint32_t u = (c & Lm) + K4;    // (c & 127) + K <= 254 per byte
+  const uint32_t ch = u | (c & H);     // c + K where it fits a byte
+  const uint32_t vB = ~(c & u);        // bit 7: c + K <= 255
+  const uint32_t clH = cl | H, chL = ch & Lm;
+  const uint32_t D0 = swar_ge(clH, cl, rd, rd & Lm), D4 = swar_ge(clH, cl, rr, rr & Lm);
+  const uint32_t D8 = swar_ge(clH, cl, ru, ru & Lm), D12 = swar_ge(clH, cl, rl, rl & Lm);
+  const uint32_t B0 = swar_ge(rd | H, rd, ch, chL), B4 = swar_ge(rr | H, rr, ch, chL);
+  const uint32_t B8 = swar_ge(ru | H, ru, ch, chL), B12 = swar_ge(rl | H, rl, ch, chL);
+  return (((D0 | D8) & (D4 | D12) & vD) | ((B0 | B8) & (B4 | B12) & vB)) & H;
 }
 
 // lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
-// compass points), two pixels per packed 16-bit operation; a quad with at least one passing pixel is queued
+// compass points), four pixels per 32-bit operation; a quad with at least one passing pixel is queued
 // (quad index | pass bits << 12).  Phase B: exact score of the queued pixels, 4 lanes per queued quad.
 __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, int x0, int y0, int T) {
-  const s16x2 Tp1 = {(short)(T + 1), (short)(T + 1)}, nTm1 = {(short)(-T - 1), (short)(-T - 1)};
+  const uint32_t K4 = (uint32_t)(T + 1) * 0x01010101u;
   // tiles whose whole score plane lies inside the testable range need no per-pixel range checks (wave-uniform)
   const bool interior = (y0 - 1 >= 3) && (y0 + FT_H < L.h - 3) && (x0 - 4 >= 3) && (x0 + FT_W + 3 < L.w - 3);
   // (sr, sq) walk the 30 x 34 quad grid without divisions: +256 quads = +7 rows +18 quads
@@ -391,16 +396,12 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
       colmask = (0xFu << lo) & (0xFu >> (4 - hi)) & 0xFu;
     }
     if (rowok && colmask) {
-      const uint32_t* p = S.raw + (sr + 3) * FR_DW + sq;        // centre row, dword of x = xq-4
+      const uint32_t* p = S.raw + mad24((uint32_t)(sr + 3), FR_DW, (uint32_t)sq);        // centre row, dword of x = xq-4
       const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
-      const uint32_t f01 = pretest_fail2(pk_bytes(Mc, Mc, 0, 1), pk_bytes(Md, Md, 0, 1), pk_bytes(Rc, Mc, 3, 4),
-                                         pk_bytes(Mu, Mu, 0, 1), pk_bytes(Mc, Lc, 1, 2), Tp1, nTm1);
-      const uint32_t f23 = pretest_fail2(pk_bytes(Mc, Mc, 2, 3), pk_bytes(Md, Md, 2, 3), pk_bytes(Rc, Mc, 5, 6),
-                                         pk_bytes(Mu, Mu, 2, 3), pk_bytes(Mc, Lc, 3, 4), Tp1, nTm1);
-      // fail bits: pixel 0 -> bit 0, pixel 1 -> bit 16, pixel 2 -> bit 2, pixel 3 -> bit 18
-      const uint32_t fb = ((f01 >> 15) | (f23 >> 13)) & 0x00050005u;
-      if (fb != 0x00050005u || false) {
-        uint32_t pm = ((fb & 1u) | ((fb >> 15) & 2u) | (fb & 4u) | ((fb >> 15) & 8u)) ^ 0xFu;
+      const uint32_t pass = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu,
+                                          __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4);
+      if (pass) {
+        uint32_t pm = ((pass >> 7) & 1u) | ((pass >> 14) & 2u) | ((pass >> 21) & 4u) | ((pass >> 28) & 8u);
         pm &= colmask;
         if (pm) S.queue[atomicAdd(&S.qcnt, 1)] = (uint16_t)(i | (pm << 12));
       }
@@ -585,7 +586,7 @@ __global__ void k_fast_thr(FastArgs A, int nframes) {
       if (acc >= need) { T = s; break; }
     }
   }
-  A.thr[i] = T;
+  A.thr[i] = min(T, 126);   // the byte-parallel pre-test needs T + 1 <= 127; any T in (20, score range] is exact
   A.redo[i] = 0;
 }
 
