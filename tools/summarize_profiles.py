@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof/) into the tracked summaries:
+
+  profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats table (our kernels + everything else)
+  profiles/<tag>_pmc_hbm_traffic.csv  FETCH_SIZE / WRITE_SIZE per kernel launch (separate passes), bytes
+  profiles/<tag>_pmc_sq.csv           SQ wave-cycle breakdown per kernel
+  profiles/<tag>_bench_n1.json        the bench line of the same box
+  profiles/traffic.json               HBM bytes per launch of the dominant kernel group (read by bench.py)
+
+FETCH_SIZE / WRITE_SIZE units: the counters are in 1 KiB units on gfx950 as collected here (x1024 -> bytes); see
+/opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section) for the wide-stream under-count noted in the CSV.
+"""
+import csv, collections, glob, json, os, sys
+
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out", "prof")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(root, "profiles")
+
+
+def short(name):
+    if "anonymous namespace" in name or name.startswith("k_"):
+        return name.split("(anonymous namespace)::")[-1].split("(")[0]
+    return name.split("(")[0][:60]
+
+
+def find(sub, pat):
+    g = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
+    return g[0] if g else None
+
+
+# 1. kernel stats
+f = find("stats", "*kernel_stats.csv")
+if f:
+    with open(f) as fi, open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as fo:
+        fo.write(fi.read())
+
+# 2. PMC passes
+def per_kernel(sub, counter):
+    f = find(sub, "*counter_collection.csv")
+    acc = collections.defaultdict(list)
+    if not f:
+        return acc
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+fetch = per_kernel("fetch", "FETCH_SIZE")
+write = per_kernel("write", "WRITE_SIZE")
+rows = []
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith("k_"):
+        continue
+    fb = 1024.0 * sum(fetch.get(k, [0])) / max(len(fetch.get(k, [1])), 1)
+    wb = 1024.0 * sum(write.get(k, [0])) / max(len(write.get(k, [1])), 1)
+    rows.append((k, len(fetch.get(k, [])), fb, wb))
+with open(os.path.join(out, tag + "_pmc_hbm_traffic.csv"), "w") as fo:
+    fo.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes): python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0\n")
+    fo.write("# workload: 1024 independent 1280x720 BGR pairs per launch (2048 frames), ORB 500; average bytes per kernel launch = counter x 1024\n")
+    fo.write("# FETCH_SIZE reads ~1:1 for 8-byte-per-lane tile staging (k_fast_*) and about one half of wide coalesced streams (guide, HBM section)\n")
+    fo.write("kernel,launches,fetch_bytes_per_launch,write_bytes_per_launch\n")
+    for k, n, fb, wb in rows:
+        fo.write("%s,%d,%.0f,%.0f\n" % (k, n, fb, wb))
+
+# traffic.json: dominant group = FAST (sample + main [+ redo]) per step
+steps = max(len(fetch.get("k_fast_main", [])), 1)
+fast_bytes = 0.0
+for k in ("k_fast_sample", "k_fast_main", "k_fast_redo", "k_fast_thr", "k_fast_verify", "k_fast"):
+    fast_bytes += 1024.0 * (sum(fetch.get(k, [])) + sum(write.get(k, []))) / steps
+if fast_bytes > 0:
+    json.dump({"fast@1280x720x1024_n500_c3": int(fast_bytes)}, open(os.path.join(out, "traffic.json"), "w"))
+
+# 3. SQ breakdown
+f = find("sq", "*counter_collection.csv")
+if f:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+             "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU"]
+    with open(os.path.join(out, tag + "_pmc_sq.csv"), "w") as fo:
+        fo.write("# rocprofv3 --kernel-trace --pmc " + " ".join(names) + " : sums over 3 launches (1 warm-up + 2 steps) of 1024 pairs\n")
+        fo.write("# fractions are of SQ_WAVE_CYCLES (WAIT_ANY = parked on s_waitcnt/barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY = issuing)\n")
+        fo.write("kernel,wave_cycles,wait_any,wait_inst_any,active_any,active_valu,active_lds,wait_inst_lds,insts_valu\n")
+        for k, v in sorted(agg.items()):
+            if not k.startswith("k_"):
+                continue
+            wc = v["SQ_WAVE_CYCLES"] or 1.0
+            fo.write("%s,%.4g,%.3f,%.3f,%.3f,%.3f,%.3f,%.3f,%.4g\n" % (
+                k, wc, v["SQ_WAIT_ANY"] / wc, v["SQ_WAIT_INST_ANY"] / wc, v["SQ_ACTIVE_INST_ANY"] / wc,
+                v["SQ_ACTIVE_INST_VALU"] / wc, v["SQ_ACTIVE_INST_LDS"] / wc, v["SQ_WAIT_INST_LDS"] / wc, v["SQ_INSTS_VALU"]))
+
+# 4. bench line
+b = os.path.join(src, "bench.json")
+if os.path.exists(b):
+    line = open(b).read().strip().splitlines()[-1]
+    json.loads(line)
+    open(os.path.join(out, tag + "_bench_n1.json"), "w").write(line + "\n")
+print("profiles/ updated with tag", tag)
