@@ -656,6 +656,7 @@ struct SelectArgs {
   float* kp_xy; uint32_t* kp_meta; float* kp_resp; int* kp_count; int* frame_flags;
   uint32_t* tmp_meta; float* tmp_resp; int* lvl_count;   // per-level staging (segments at EvhLevel.kp_base)
   int kcap;
+  int k1cap, k2cap;   // LDS capacities of k_select (stage-1 / stage-2 survivors of one level)
 };
 
 __device__ __forceinline__ float harris_response(const uint8_t* img, int stride, int x0, int y0) {
@@ -689,10 +690,13 @@ __device__ __forceinline__ uint32_t f32_order_key(float v) {
 // one workgroup per (level, frame): both retainBest stages + Harris + canonical order; results go to the level's
 // segment of the frame's staging arrays, k_pack then concatenates the eight segments.
 __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
-  __shared__ uint32_t keys[EVH_K1CAP];
-  __shared__ float resp[EVH_K1CAP];
-  __shared__ uint32_t sel[EVH_K2CAP];
-  __shared__ float selr[EVH_K2CAP];
+  // dynamic LDS, sized by the launcher from the key-point budget: keys[k1cap] | resp[k1cap] | sel[k2cap] | selr[k2cap]
+  extern __shared__ uint32_t sel_dyn[];
+  const int K1CAP = A.k1cap, K2CAP = A.k2cap;
+  uint32_t* keys = sel_dyn;
+  float* resp = reinterpret_cast<float*>(keys + K1CAP);
+  uint32_t* sel = reinterpret_cast<uint32_t*>(resp + K1CAP);
+  float* selr = reinterpret_cast<float*>(sel + K2CAP);
   __shared__ uint32_t hist[256];
   __shared__ int sh_i[8];  // 0: cut / digit, 1: k1, 2: k2, 3: remaining
   const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -725,12 +729,12 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
       uint32_t c = cand[i];
       if ((c >> 24) >= cut) {
         int slot = atomicAdd(&sh_i[1], 1);
-        if (slot < EVH_K1CAP) keys[slot] = c;
+        if (slot < K1CAP) keys[slot] = c;
       }
     }
     __syncthreads();
     int k1 = sh_i[1];
-    if (k1 > EVH_K1CAP) { overflow = true; k1 = EVH_K1CAP; }
+    if (k1 > K1CAP) { overflow = true; k1 = K1CAP; }
     // ---- Harris response of every stage-1 survivor
     const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
     for (int j = tid; j < k1; j += 256) {
@@ -769,11 +773,11 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
     for (int j = tid; j < k1; j += 256)
       if (resp[j] >= cutf) {
         int slot = atomicAdd(&sh_i[2], 1);
-        if (slot < EVH_K2CAP) { sel[slot] = keys[j]; selr[slot] = resp[j]; }
+        if (slot < K2CAP) { sel[slot] = keys[j]; selr[slot] = resp[j]; }
       }
     __syncthreads();
     k2 = sh_i[2];
-    if (k2 > EVH_K2CAP) { overflow = true; k2 = EVH_K2CAP; }
+    if (k2 > K2CAP) { overflow = true; k2 = K2CAP; }
     if (k2 > L.kp_cap) { overflow = true; k2 = L.kp_cap; }
     // ---- canonical order inside the level: ascending (y, x) by rank counting
     for (int j = tid; j < k2; j += 256) {
@@ -1066,7 +1070,14 @@ int evh_launch_select(evh_ctx* c, int nframes) {
   A.frame_flags = c->d_frame_flags; A.kcap = c->kcap;
   A.tmp_meta = c->d_tmp_meta; A.tmp_resp = c->d_tmp_resp; A.lvl_count = c->d_lvl_count;
   EVH_HIP(c, hipMemsetAsync(c->d_frame_flags, 0, sizeof(int) * (size_t)nframes, c->stream));
-  hipLaunchKernelGGL(k_select, dim3(EVH_NLEVELS, nframes), dim3(256), 0, c->stream, A);
+  // LDS capacities follow the largest per-level quota q0: stage 1 keeps 2*q0 + score ties, stage 2 q0 + response ties
+  // (overflow is flagged per frame -> EVH_PAIR_CAPACITY, never truncated silently); bounded by the fixed maxima
+  int q0 = 0;
+  for (int l = 0; l < EVH_NLEVELS; l++) q0 = std::max(q0, A.lv[l].quota);
+  A.k1cap = std::min(EVH_K1CAP, std::max(1024, (4 * q0 + 63) / 64 * 64));
+  A.k2cap = std::min(EVH_K2CAP, std::max(256, (q0 + q0 / 4 + 64 + 63) / 64 * 64));
+  const size_t lds = sizeof(uint32_t) * 2 * ((size_t)A.k1cap + A.k2cap);
+  hipLaunchKernelGGL(k_select, dim3(EVH_NLEVELS, nframes), dim3(256), lds, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
