@@ -702,6 +702,30 @@ __device__ __forceinline__ uint32_t f32_order_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// All 256 threads: the largest bin d whose inclusive suffix sum (bins d..255) reaches `target`, and the sum of the bins
+// above d.  Equals the serial scan "from 255 down, stop at the first bin where the running sum reaches target".
+// hist must be complete (barrier before the call); the caller guarantees that the total reaches target.  sh: int[12].
+__device__ __forceinline__ int block_suffix_cut(const uint32_t* hist, int target, int* sh, int& above) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int v = (int)hist[tid];
+  int s = v;                                    // inclusive suffix sum inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(s, o); if (lane + o < 64) s += t; }
+  if (lane == 0) sh[wv] = s;
+  __syncthreads();
+  int hi = 0;
+  for (int w = wv + 1; w < 4; w++) hi += sh[w];
+  const int suf = s + hi;
+  const unsigned long long m = __ballot(suf >= target);
+  if (lane == 0) sh[4 + wv] = m ? (wv * 64 + 63 - (int)__clzll(m)) : -1;
+  __syncthreads();
+  const int d = max(max(sh[4], sh[5]), max(max(sh[6], sh[7]), 0));
+  if (tid == d) sh[8] = suf - v;
+  __syncthreads();
+  above = sh[8];
+  return d;
+}
+
 // one workgroup per (level, frame): both retainBest stages + Harris + canonical order; results go to the level's
 // segment of the frame's staging arrays, k_pack then concatenates the eight segments.
 __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
@@ -713,7 +737,8 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
   uint32_t* sel = reinterpret_cast<uint32_t*>(resp + K1CAP);
   float* selr = reinterpret_cast<float*>(sel + K2CAP);
   __shared__ uint32_t hist[256];
-  __shared__ int sh_i[8];  // 0: cut / digit, 1: k1, 2: k2, 3: remaining
+  __shared__ int sh_i[8];  // 1: k1, 2: k2
+  __shared__ int sh_cut[12];
   const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   const EvhLevel L = A.lv[l];
   const uint32_t* cand = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
@@ -730,16 +755,8 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
     if (n > 2 * q)
       for (int i = tid; i < n; i += 256) atomicAdd(&hist[cand[i] >> 24], 1u);
     __syncthreads();
-    if (tid == 0) {
-      int cut = 0;
-      if (n > 2 * q) {
-        int acc = 0;
-        for (int s = 255; s >= 0; s--) { acc += (int)hist[s]; if (acc >= 2 * q) { cut = s; break; } }
-      }
-      sh_i[0] = cut;
-    }
-    __syncthreads();
-    const uint32_t cut = (uint32_t)sh_i[0];
+    uint32_t cut = 0;
+    if (n > 2 * q) { int above; cut = (uint32_t)block_suffix_cut(hist, 2 * q, sh_cut, above); }   // workgroup-uniform branch
     for (int i = tid; i < n; i += 256) {
       uint32_t c = cand[i];
       if ((c >> 24) >= cut) {
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
     float cutf = -INFINITY;
     if (k1 > q) {
       uint32_t prefix = 0;
-      if (tid == 0) sh_i[3] = q;
+      int rem = q;
       for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
         hist[tid] = 0;
@@ -772,15 +789,10 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
           if (in) atomicAdd(&hist[(u >> shift) & 0xFFu], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-          int rem = sh_i[3], acc = 0, d = 255;
-          for (; d > 0; d--) { if (acc + (int)hist[d] >= rem) break; acc += (int)hist[d]; }
-          sh_i[3] = rem - acc;
-          sh_i[0] = d;
-        }
-        __syncthreads();
-        prefix |= (uint32_t)sh_i[0] << shift;
-        __syncthreads();
+        int above;
+        const int d = block_suffix_cut(hist, rem, sh_cut, above);
+        rem -= above;
+        prefix |= (uint32_t)d << shift;
       }
       uint32_t u = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
       cutf = __uint_as_float(u);
