@@ -19,9 +19,9 @@ out = os.path.join(root, "profiles")
 
 
 def short(name):
-    if "anonymous namespace" in name or name.startswith("k_"):
-        return name.split("(anonymous namespace)::")[-1].split("(")[0]
-    return name.split("(")[0][:60]
+    if name.startswith("(anonymous namespace)::"):
+        name = name[len("(anonymous namespace)::"):]
+    return name.split("(")[0].split("<")[0][:60]
 
 
 def find(sub, pat):
