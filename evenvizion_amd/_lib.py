@@ -40,6 +40,8 @@ SIGNATURES = {
     "evh_orb_count": (_i, [_vp, _i]),
     "evh_orb_capacity": (_i, [_vp]),
     "evh_orb_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evh_orb_detect_compute": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "evh_resize_area_u8c3": (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
     "evh_orb_level_info": (_i, [_vp, _i, _pi, _pi, _pi, C.POINTER(C.c_float)]),
     "evh_orb_download_level": (_i, [_vp, _i, _i, _vp]),
     "evh_orb_download_candidates": (_i, [_vp, _i, _i, _vp, _i]),
@@ -157,6 +159,11 @@ class Context:
         self._check(self.lib.evh_resize_area_u8(self.h, src.data_ptr(), n, sw, sh, cn, sw * cn, sw * sh * cn,
                                                 dst.data_ptr(), dw, dh, dw * cn, dw * dh * cn))
 
+    def resize_area_bgr(self, src, dst):
+        """One BGR image: src CUDA uint8 [sh,sw,3] -> dst [dh,dw,3] (imutils.resize / INTER_AREA)."""
+        sh, sw = src.shape[:2]; dh, dw = dst.shape[:2]
+        self._check(self.lib.evh_resize_area_u8c3(self.h, src.data_ptr(), sw, sh, dst.data_ptr(), dw, dh))
+
     def set_fast_lift(self, on=True):
         self._check(self.lib.evh_set_fast_lift(self.h, int(bool(on))))
 
@@ -174,6 +181,18 @@ class Context:
         n, h, w = frames.shape[:3]
         cn = 1 if frames.dim() == 3 else frames.shape[3]
         self._check(self.lib.evh_orb_detect_batch(self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures))
+
+    def orb_detect_compute(self, frame, nfeatures=500):
+        """One frame (CUDA uint8 [h,w] or [h,w,3]) -> (xy f32[n,2], desc u8[n,32], octave i32[n]); the single-frame
+        form of cv2.ORB_create().detectAndCompute (frame_processing.py:60-61)."""
+        h, w = frame.shape[:2]
+        cn = 1 if frame.dim() == 2 else frame.shape[2]
+        cap = self.lib.evh_orb_capacity(self.h)
+        xy = np.zeros((cap, 2), np.float32); desc = np.zeros((cap, 32), np.uint8); oc = np.zeros(cap, np.int32)
+        n = C.c_int(0)
+        self._check(self.lib.evh_orb_detect_compute(self.h, frame.data_ptr(), w, h, cn, nfeatures, _hp(xy), _hp(desc),
+                                                    _hp(oc), C.byref(n)))
+        return xy[:n.value].copy(), desc[:n.value].copy(), oc[:n.value].copy()
 
     def orb_download(self, frame):
         cap = self.lib.evh_orb_capacity(self.h)

@@ -352,6 +352,11 @@ int evh_resize_area_u8(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int s
                                 dst_img_stride);
 }
 
+int evh_resize_area_u8c3(evh_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh) {
+  return evh_resize_area_u8(c, d_src, 1, sw, sh, 3, (int64_t)sw * 3, (int64_t)sw * sh * 3, d_dst, dw, dh, (int64_t)dw * 3,
+                            (int64_t)dw * dh * 3);
+}
+
 int evh_fixed_plane_field(evh_ctx* c, const double* h_Hsup, int n, int w, int h, double* d_field, double* h_max) {
   if (!c || !h_Hsup || !h_max || n < 1 || w < 1 || h < 1) return evh_fail(c, EVH_ERR_INVALID, "evh_fixed_plane_field: bad argument");
   if (n > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "evh_fixed_plane_field: at most 65535 matrices per call");
@@ -431,6 +436,17 @@ int evh_orb_download(evh_ctx* c, int frame, float* h_xy, uint8_t* h_desc, int32_
     if (h_lxy) { h_lxy[2 * i] = (int32_t)(meta[i] & 0xFFFu); h_lxy[2 * i + 1] = (int32_t)((meta[i] >> 12) & 0xFFFu); }
   }
   return n;
+}
+
+int evh_orb_detect_compute(evh_ctx* c, const uint8_t* d_frame, int w, int h, int channels, int nfeatures, float* h_xy,
+                           uint8_t* h_desc, int32_t* h_octave, int* h_count) {
+  if (!c) return EVH_ERR_INVALID;
+  int rc = evh_orb_detect_batch(c, d_frame, 1, w, h, channels, (int64_t)w * channels, (int64_t)w * h * channels, nfeatures);
+  if (rc != EVH_SUCCESS) return rc;
+  const int n = evh_orb_download(c, 0, h_xy, h_desc, h_octave, nullptr, nullptr, nullptr);
+  if (n < 0) return n;
+  if (h_count) *h_count = n;
+  return EVH_SUCCESS;
 }
 
 int evh_orb_level_info(const evh_ctx* c, int level, int* w, int* h, int* quota, float* scale) {

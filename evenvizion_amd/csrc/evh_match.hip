@@ -18,7 +18,8 @@ __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t acc) {
 #endif
 }
 
-// one workgroup (256 threads) per pair; a thread owns queries tid, tid+256, ... ; train set streamed through LDS
+// one workgroup (256 threads) per (pair, chunk of 256 queries): blockIdx.y = chunk, so that a few pairs with many
+// descriptors (4K frames, N = 4000) still fill the chip; the train set is streamed through LDS by every chunk
 __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
   __shared__ uint4 tdesc[MT_TILE * 2];
   __shared__ uint32_t tnorm[MT_TILE];
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
   const uint4* T = reinterpret_cast<const uint4*>(A.t + (int64_t)ts * A.slot_bytes);
   int32_t* oidx = A.idx + (int64_t)p * A.out_stride * 2;
   uint32_t* od2 = A.d2 + (int64_t)p * A.out_stride * 2;
-  for (int q0 = 0; q0 < nq; q0 += 256) {
+  for (int q0 = blockIdx.y * 256; q0 < nq; q0 += 256 * gridDim.y) {   // workgroup-uniform bounds
     const int qi = q0 + tid;
     const bool act = qi < nq;
     uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
@@ -181,7 +182,10 @@ __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
 
 int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs) {
   if (npairs <= 0) return EVH_SUCCESS;
-  hipLaunchKernelGGL(k_knn2, dim3(npairs), dim3(256), 0, c->stream, A);
+  // chunks of 256 queries in grid.y, bounded by the largest possible query count
+  const int nq_max = A.nq_arr ? A.out_stride : A.nq_fixed;
+  const int chunks = std::max(1, std::min((nq_max + 255) / 256, 64));
+  hipLaunchKernelGGL(k_knn2, dim3(npairs, chunks), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }

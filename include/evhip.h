@@ -86,6 +86,9 @@ int evh_resize_area_u8(evh_ctx* ctx, const uint8_t* d_src, int nimg, int sw, int
                        int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
                        int64_t dst_img_stride);
 
+/* BGR convenience form of the same call (one image): cn = 3, tight rows.                                        */
+int evh_resize_area_u8c3(evh_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh);
+
 /* ---- N3: fixed-plane coordinate field of the heat-map (processing_visualization.py:407-408,419) ------- */
 /* For each of n superposed matrices h_Hsup f64[n,9]: (u,v) = H.(x,y,1) for every pixel of a w x h grid (what
  * np.apply_along_axis(homography_transformation, 2, template, H) computes) and max over the grid of max(u,v) --
@@ -112,6 +115,11 @@ int evh_orb_capacity(const evh_ctx* ctx);
  * response f32[n], angle f32[n] (degrees).  Returns n. Canonical order: (octave, y, x).                      */
 int evh_orb_download(evh_ctx* ctx, int frame, float* h_xy, uint8_t* h_desc, int32_t* h_octave, int32_t* h_lxy,
                      float* h_response, float* h_angle);
+/* single-frame convenience form of detectAndCompute (frame_processing.py:60-61): one device frame in (tight
+ * rows: row_stride = w * channels), features to HOST arrays sized evh_orb_capacity() rows (any may be NULL),
+ * number of key points in *h_count.  Equivalent to evh_orb_detect_batch(nframes = 1) + evh_orb_download(0).   */
+int evh_orb_detect_compute(evh_ctx* ctx, const uint8_t* d_frame, int w, int h, int channels, int nfeatures,
+                           float* h_xy, uint8_t* h_desc, int32_t* h_octave, int* h_count);
 /* test/inspection hooks: pyramid level geometry + contents, FAST candidates (packed score<<24|y<<12|x) */
 int evh_orb_level_info(const evh_ctx* ctx, int level, int* w, int* h, int* quota, float* scale);
 int evh_orb_download_level(evh_ctx* ctx, int frame, int level, uint8_t* h_pixels /* h*w tight */);

@@ -319,6 +319,24 @@ def test_resize_area(ctx):
         assert np.array_equal(out.cpu().numpy()[0], want)
 
 
+def test_single_frame_convenience_entries(ctx):
+    """evh_orb_detect_compute / evh_resize_area_u8c3 (the single-image forms SURVEY 8b lists) == the batch entries."""
+    a, _, _ = S.make_pair(77, 640, 360)
+    bgr = S.gray_to_bgr(a)
+    xy, desc, oc = ctx.orb_detect_compute(dev(bgr), 500)
+    o = O.orb_detect(a)
+    assert np.array_equal(xy, o["xy"]) and np.array_equal(desc, o["desc"]) and np.array_equal(oc, o["octave"])
+    xy1, desc1, _ = ctx.orb_detect_compute(dev(a), 500)          # gray input
+    assert np.array_equal(xy1, xy) and np.array_equal(desc1, desc)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (658, 1170, 3), dtype=np.uint8)
+    dw, dh = O.resize_dims(1170, 658, 400)
+    out = torch.zeros((dh, dw, 3), dtype=torch.uint8, device="cuda")
+    ctx.resize_area_bgr(dev(img), out)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy(), O.resize_area(img, dw, dh))
+
+
 # ---- the Python mirror of evenvizion.processing, end to end on the GPU -----------------------------------------------
 def test_python_api_mirror_vs_oracle():
     from evenvizion_amd.processing import FrameProcessing, KeyPoints, NoMatchesException, compute_homography, \
