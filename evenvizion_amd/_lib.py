@@ -52,6 +52,8 @@ SIGNATURES = {
     "evh_static_filter": (_i, [_vp, _vp, _vp, _i, _vp, _pi]),
     "evh_pair_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp]),
     "evh_stream_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
+    "evh_stream_static_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _i, _vp, _vp]),
+    "evh_stream_scan": (_i, [_vp, _vp, _i, _vp, _vp, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "evh_pair_from_slots": (_i, [_vp, _i, _i, _vp, _vp, _pi]),
     "evh_match_static_from_slots": (_i, [_vp, _i, _i, _vp, _i, _pi, _pi]),
     "evh_compute_homography": (_i, [_vp, _vp, _i, _vp, _vp, _pi]),
@@ -269,6 +271,62 @@ class Context:
             self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures, float(thr), int(max_iters), float(conf),
             int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,
             state_out.data_ptr() if state_out is not None else None, out_H.data_ptr(), out_status.data_ptr()))
+
+    def _torch_stream(self):
+        """The context's (non-blocking) HIP stream as a torch stream, for ordering against torch work."""
+        import torch
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.stream, device=self.device)
+        return self._ext_stream
+
+    def order_after_torch(self):
+        """Kernels enqueued by this context from now on wait for the work already on torch's current stream."""
+        import torch
+        self._torch_stream().wait_stream(torch.cuda.current_stream(self.device))
+
+    def order_torch_after(self):
+        """torch's current stream waits for everything this context has enqueued so far (main and solve stream)."""
+        import torch
+        self.solve_wait()
+        torch.cuda.current_stream(self.device).wait_stream(self._torch_stream())
+
+    def stream_static_batch(self, frames, nfeatures=500, thr=3.0, max_iters=2000, conf=0.995, force_max_iters=False):
+        """Phase 1 of the two-phase stream path (evh_stream_static_batch): frames CUDA uint8 [n,h,w(,3)] ->
+        (rows f32[n-1,cap,4], counts i32[n-1], status1 i32[n-1]) as CUDA tensors.  Asynchronous, but ordered with
+        torch's current stream on both sides (inputs produced by torch ops, outputs consumed by torch ops / RCCL)."""
+        import torch
+        n, h, w = frames.shape[:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        cap = self.lib.evh_orb_capacity(self.h)
+        rows = torch.zeros((max(n - 1, 0), cap, 4), dtype=torch.float32, device=frames.device)
+        counts = torch.zeros(max(n - 1, 0), dtype=torch.int32, device=frames.device)
+        status1 = torch.zeros(max(n - 1, 0), dtype=torch.int32, device=frames.device)
+        if n < 2:
+            return rows, counts, status1          # an empty block (more ranks than pairs)
+        self.order_after_torch()
+        self._check(self.lib.evh_stream_static_batch(
+            self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures, float(thr), int(max_iters), float(conf),
+            int(bool(force_max_iters)), rows.data_ptr(), cap, counts.data_ptr(), status1.data_ptr()))
+        self.order_torch_after()
+        return rows, counts, status1
+
+    def stream_scan(self, rows, counts, status1, state_in=None, state_out=None, thr=3.0, max_iters=2000, conf=0.995,
+                    force_max_iters=False):
+        """Phase 2 (evh_stream_scan): the sequential compute_homography / matrix_superposition scan over all pairs in
+        stream order -> (H f64[npairs,9], status i32[npairs]) CUDA tensors.  Asynchronous, ordered with torch's
+        current stream like stream_static_batch."""
+        import torch
+        npairs, cap = rows.shape[0], rows.shape[1]
+        rows = rows.contiguous(); counts = counts.contiguous(); status1 = status1.contiguous()
+        H = torch.zeros((npairs, 9), dtype=torch.float64, device=rows.device)
+        st = torch.zeros(npairs, dtype=torch.int32, device=rows.device)
+        self.order_after_torch()
+        self._check(self.lib.evh_stream_scan(
+            self.h, rows.data_ptr(), cap, counts.data_ptr(), status1.data_ptr(), npairs, float(thr), int(max_iters),
+            float(conf), int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,
+            state_out.data_ptr() if state_out is not None else None, H.data_ptr(), st.data_ptr()))
+        self.order_torch_after()
+        return H, st
 
     def match_static_from_slots(self, cur_slot, prev_slot):
         cap = self.lib.evh_orb_capacity(self.h)

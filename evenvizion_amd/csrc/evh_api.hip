@@ -640,6 +640,46 @@ int evh_compute_homography(evh_ctx* c, const float* h_pts, int n, const double* 
   return EVH_SUCCESS;
 }
 
+int evh_stream_static_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
+                            int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
+                            int ransac_max_iters, double ransac_conf, int force_max_iters, float* d_rows, int row_cap,
+                            int32_t* d_counts, int32_t* d_status1) {
+  if (!c || !d_frames || !d_rows || !d_counts || !d_status1 || nframes < 2)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_stream_static_batch: bad argument");
+  if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "block needs more frame slots than max_frames");
+  if (row_cap != c->kcap) return evh_fail(c, EVH_ERR_INVALID, "row_cap must equal evh_orb_capacity()");
+  const int npairs = nframes - 1;
+  int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
+  if (rc) return rc;
+  if ((rc = match_pairs(c, npairs, 1, 1, 0, 1))) return rc;      // orders itself behind a pending async solve
+  EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
+  { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC); rc = evh_launch_ransac_static(c, R, npairs); }
+  if (rc) return rc;
+  EVH_HIP(c, hipMemcpyAsync(d_rows, c->d_pts2, sizeof(float) * 4 * (size_t)c->kcap * npairs, hipMemcpyDeviceToDevice, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(d_counts, c->d_npts2, sizeof(int) * (size_t)npairs, hipMemcpyDeviceToDevice, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(d_status1, c->d_pstatus, sizeof(int) * (size_t)npairs, hipMemcpyDeviceToDevice, c->stream));
+  return EVH_SUCCESS;
+}
+
+int evh_stream_scan(evh_ctx* c, const float* d_rows, int row_cap, const int32_t* d_counts, const int32_t* d_status1,
+                    int npairs, double ransac_thr, int ransac_max_iters, double ransac_conf, int force_max_iters,
+                    const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status) {
+  if (!c || !d_rows || !d_counts || !d_status1 || !d_H || !d_status || npairs < 1)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_stream_scan: bad argument");
+  if (row_cap < 1 || row_cap > c->kcap) return evh_fail(c, EVH_ERR_CAPACITY, "row_cap larger than evh_orb_capacity()");
+  if (((uintptr_t)d_rows) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_rows must be 16-byte aligned");
+  { int jr = join_solve(c); if (jr) return jr; }                  // the scan uses slot 0 of the pair scratch
+  EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
+  R.pts2 = const_cast<float*>(d_rows); R.npts2 = const_cast<int*>(d_counts); R.status = const_cast<int*>(d_status1);
+  R.row_stride = row_cap; R.info = nullptr;
+  R.H = d_H; R.out_status = d_status;
+  if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
+  R.state_out = d_state_out;
+  int rc;
+  { EvhProfScope ps(c, EVH_ST_RANSAC_FINAL); rc = evh_launch_ransac_final(c, R, npairs, 1); }
+  return rc;
+}
+
 int evh_pair_from_slots(evh_ctx* c, int cur_slot, int prev_slot, const double* h_Hsup, double* h_H, int* h_status) {
   if (!c || !h_H || !h_status) return evh_fail(c, EVH_ERR_INVALID, "evh_pair_from_slots: bad argument");
   int n = 0, st = 0;

@@ -881,9 +881,9 @@ __global__ __launch_bounds__(64) void k_ransac_final_stream(EvhRansacArgs A, int
     if (st == EVH_PAIR_OK) {
       const int n = A.npts2[p];
       const float* rows = A.pts2 + (int64_t)p * A.row_stride * 4;
-      st = compute_homography_wave(S, lane, rows, n, first ? nullptr : Hsup, A, A.mask + (int64_t)p * A.row_stride,
-                                   A.pts + (int64_t)p * A.row_stride * 4, A.crow + (int64_t)p * A.row_stride * 4,
-                                   A.lm + (int64_t)p * A.row_stride * 4, A.info ? A.info + 8 * p + 4 : nullptr);
+      // the scan is sequential: one pair's worth of scratch (slot 0) serves any number of pairs
+      st = compute_homography_wave(S, lane, rows, n, first ? nullptr : Hsup, A, A.mask, A.pts, A.crow, A.lm,
+                                   A.info ? A.info + 8 * p + 4 : nullptr);
     }
     WSYNC();
     if (lane == 0) A.out_status[p] = st;

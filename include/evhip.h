@@ -163,6 +163,24 @@ int evh_stream_homography_batch(evh_ctx* ctx, const uint8_t* d_frames, int nfram
                                 int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
                                 int ransac_max_iters, double ransac_conf, int force_max_iters,
                                 const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status);
+/* Two-phase form of the stream path, for sharding ONE stream over several GPUs with the reference's semantics
+ * (video_processing.py:67-105).  Phase 1 is independent per pair and runs wherever the frames are:
+ * detect, match, ratio/unique filter, RANSAC #1, static filter (frame_processing.py:91-98, matching.py:131-163) on
+ * nframes consecutive frames -> nframes-1 pairs; it leaves per pair the static rows f32[row_cap,4] (ax,ay,bx,by),
+ * their count and the phase-1 status (EVH_PAIR_*) in CALLER device buffers; row_cap must equal evh_orb_capacity().
+ * Phase 2 is the sequential part (compute_homography with the running superposition, utils.py:328-363, and
+ * matrix_superposition, utils.py:118-145): it scans npairs pairs (any number -- rows gathered from all shards) in
+ * stream order from d_state_in (f64[18] {H_sup, H_prev} or NULL at the start of the stream) and writes H f64[9] and
+ * the final status per pair, plus the state after the last pair.  Running phase 1 on blocks that overlap by one
+ * frame and phase 2 once over the concatenated rows gives bit-identical results to evh_stream_homography_batch on
+ * the whole stream.  Neither call synchronises.                                                                  */
+int evh_stream_static_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int w, int h, int channels,
+                            int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
+                            int ransac_max_iters, double ransac_conf, int force_max_iters, float* d_rows, int row_cap,
+                            int32_t* d_counts, int32_t* d_status1);
+int evh_stream_scan(evh_ctx* ctx, const float* d_rows, int row_cap, const int32_t* d_counts, const int32_t* d_status1,
+                    int npairs, double ransac_thr, int ransac_max_iters, double ransac_conf, int force_max_iters,
+                    const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status);
 /* the same per-pair body starting from features already resident in the context (frame slots): used by the
  * Python FrameProcessing/KeyPoints mirror.  cur/prev are frame slots of the last evh_orb_detect_batch.
  * h_Hsup: f64[9] or NULL.  h_H f64[9]; returns the pair status in *h_status.                                 */

@@ -306,6 +306,40 @@ def test_stream_vs_oracle(ctx):
         assert np.allclose(Hg[p], Ho[p], rtol=1e-9, atol=1e-12)
 
 
+def test_two_phase_stream_equals_whole_stream(ctx):
+    """phase 1 on blocks that overlap by one frame (what 3 GPUs would each do) + ONE phase-2 scan over the
+    concatenated static rows == the stream path on the whole stream, bit for bit; and == the oracle."""
+    from evenvizion_amd.sharding import stream_block
+    frames, _ = S.make_stream(21, 8, 400, 224)       # the module context holds 8 frame slots
+    n = len(frames) - 1
+    d = dev(frames)
+    H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+    st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    ctx.pair_homography_batch(d, n, 1, H, st)
+    ctx.synchronize()
+    for world in (1, 3):
+        parts = []
+        for r in range(world):
+            f_lo, f_hi, p_lo, p_hi = stream_block(len(frames), r, world)
+            parts.append(ctx.stream_static_batch(d[f_lo:f_hi].contiguous()))
+            assert parts[-1][0].shape[0] == p_hi - p_lo
+        rows = torch.cat([p[0] for p in parts]); counts = torch.cat([p[1] for p in parts]); st1 = torch.cat([p[2] for p in parts])
+        state = torch.zeros(18, dtype=torch.float64, device="cuda")
+        H2, st2 = ctx.stream_scan(rows, counts, st1, state_out=state)
+        ctx.synchronize()
+        assert torch.equal(st2, st) and torch.equal(H2, H)
+    # chunked scan with carried state == one scan
+    k = 3
+    sa = torch.zeros(18, dtype=torch.float64, device="cuda")
+    Ha, sta = ctx.stream_scan(rows[:k], counts[:k], st1[:k], state_out=sa)
+    Hb, stb = ctx.stream_scan(rows[k:], counts[k:], st1[k:], state_in=sa)
+    ctx.synchronize()
+    assert torch.equal(torch.cat([Ha, Hb]), H) and torch.equal(torch.cat([sta, stb]), st)
+    Ho, so, _ = O.stream_gray(frames)
+    assert np.array_equal(st.cpu().numpy(), so)
+    assert np.allclose(H.cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
+
+
 def test_resize_area(ctx):
     rng = np.random.default_rng(4)
     for (sw, sh, width, cn) in [(1170, 658, 400, 3), (1280, 720, 320, 3), (800, 600, 400, 1), (900, 300, 300, 3),

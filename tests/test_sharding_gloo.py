@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from evenvizion_amd.sharding import gather_pair_records, shard_range
+from evenvizion_amd.sharding import gather_pair_records, shard_range, sharded_stream_homographies, stream_block
 
 
 def test_shard_range_partitions():
@@ -53,3 +53,63 @@ def test_single_process_passthrough():
     H = torch.zeros(3, 9, dtype=torch.float64); st = torch.zeros(3, dtype=torch.int32)
     H2, st2 = gather_pair_records(H, st, 3)
     assert H2.shape == (3, 9) and torch.equal(st2, st)
+
+
+# ---- one stream over several ranks: phase 1 sharded with a one-frame overlap, rows gathered, phase 2 redundant ------
+CAP = 5
+
+
+def _fake_static(f_lo, f_hi):
+    """stand-in for Context.stream_static_batch: rows that encode the pair's two frame indices"""
+    n = max(f_hi - f_lo - 1, 0)
+    rows = torch.zeros(n, CAP, 4, dtype=torch.float32)
+    counts = torch.zeros(n, dtype=torch.int32)
+    status = torch.zeros(n, dtype=torch.int32)
+    for i in range(n):
+        p = f_lo + i
+        rows[i, :, 0] = p; rows[i, :, 1] = p + 1; rows[i, :, 2] = torch.arange(CAP); rows[i, :, 3] = 7 * p
+        counts[i] = 1 + p % CAP
+        status[i] = p % 3
+    return rows, counts, status
+
+
+def _fake_scan(rows, counts, status):
+    """stand-in for Context.stream_scan: an order-dependent running quantity"""
+    acc = torch.cumsum(rows[:, 0, 0].double() * 3 + counts.double() + status.double(), 0)
+    return acc, status
+
+
+def _stream_worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    acc, st = sharded_stream_homographies(_fake_static, _fake_scan, n_frames)
+    want_acc, want_st = _fake_scan(*_fake_static(0, n_frames))
+    q.put((rank, bool(torch.equal(acc, want_acc) and torch.equal(st, want_st))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stream_block_covers_every_pair_once():
+    for n_frames in (2, 3, 9, 10, 101):
+        for world in (1, 2, 3, 8):
+            pairs = []
+            for r in range(world):
+                f_lo, f_hi, p_lo, p_hi = stream_block(n_frames, r, world)
+                assert (p_hi == p_lo and f_hi == f_lo) or (f_lo == p_lo and f_hi == p_hi + 1)
+                pairs += list(range(p_lo, p_hi))
+            assert pairs == list(range(n_frames - 1))
+
+
+def test_sharded_stream_world2():
+    for n_frames in (10, 2):          # 2 frames = 1 pair: rank 1 owns an empty block
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(60)
+        assert res == [(0, True), (1, True)]
