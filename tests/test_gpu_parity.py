@@ -238,6 +238,60 @@ def test_pair_batch_vs_oracle(ctx, w, h, npairs):
                 assert corner_err(Hg[p], Ho[p], w, h) <= 0.05
 
 
+def test_failure_statuses_in_a_batch_and_in_a_stream(ctx):
+    """The reference's failure branches (matching.py:104-107, :113; video_processing.py:83-105 none_H_processing):
+    a flat frame has no descriptors (status 1), unrelated / low-contrast frames leave < 4 matches (status 2); good
+    pairs in the same batch are unaffected; in a stream a failing pair repeats the previous H and the superposition
+    carries on; a failing FIRST pair has no previous H (the reference raises: NaN + stop here)."""
+    w, h = 400, 224
+    a0, b0, _ = S.make_pair(1, w, h)
+    a1, b1, _ = S.make_pair(2, w, h)
+    flat = np.full((h, w), 128, np.uint8)
+    lc0 = ((a0.astype(np.int32) - 128) // 6 + 128).astype(np.uint8)
+    lc1 = ((b0.astype(np.int32) - 128) // 6 + 128).astype(np.uint8)
+    pairs = [(a0, b0), (flat, b0), (a0, flat), (a0, b1), (a1, b1), (lc0, lc1)]
+    frames = np.stack([f for p in pairs for f in p])
+    n = len(pairs)
+    H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+    st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    from evenvizion_amd._lib import Context
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=2 * n)
+    try:
+        c.pair_homography_batch(dev(frames), n, 0, H, st)
+        c.synchronize()
+        Ho, so = O.pairs_gray_batch(frames)
+        assert list(so) == [0, 1, 1, 2, 0, 2]
+        assert np.array_equal(st.cpu().numpy(), so)
+        Hg = H.cpu().numpy().reshape(-1, 3, 3)
+        for p in range(n):
+            if so[p] == 0:
+                assert np.allclose(Hg[p], Ho[p], rtol=1e-9, atol=1e-12)
+        # stream with a failure in the middle: H repeats, the scan continues
+        fr, _ = S.make_stream(9, 6, w, h)
+        s1 = np.stack([fr[0], fr[1], flat, fr[2], fr[3], fr[4]])
+        H1 = torch.zeros(5, 9, dtype=torch.float64, device="cuda")
+        st1 = torch.full((5,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(s1), 5, 1, H1, st1)
+        c.synchronize()
+        Ho1, so1, rc1 = O.stream_gray(s1)
+        assert rc1 == -1 and list(so1) == [0, 1, 1, 0, 0]
+        assert np.array_equal(st1.cpu().numpy(), so1)
+        H1g = H1.cpu().numpy().reshape(-1, 3, 3)
+        assert np.allclose(H1g, Ho1, rtol=1e-9, atol=1e-12)
+        assert np.array_equal(H1g[1], H1g[0]) and np.array_equal(H1g[2], H1g[0])
+        # stream whose first pair fails
+        s2 = np.stack([flat, fr[1], fr[2], fr[3]])
+        H2 = torch.zeros(3, 9, dtype=torch.float64, device="cuda")
+        st2 = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(s2), 3, 1, H2, st2)
+        c.synchronize()
+        _, so2, rc2 = O.stream_gray(s2)
+        assert rc2 == 0 and so2[0] == 1
+        assert st2.cpu().numpy()[0] == 1 and bool(torch.isnan(H2[0]).all())
+    finally:
+        c.close()
+
+
 def test_async_solve_back_to_back_batches(ctx):
     """RANSAC on the solve stream overlapping the next batch's detect kernels must not change any result."""
     batches = [S.make_pair_batch(30 + i, 3, 400, 224)[0] for i in range(3)]
