@@ -40,6 +40,34 @@ struct RansacLds {
   int ib[8];           // ints: proceed flags, counts
 };
 
+// Cross-lane moves inside a 16-lane group as DPP register moves (a VALU op) instead of ds_bpermute round trips.
+// The four controls pair every lane with: its xor-1 / xor-2 neighbour (quad permutes), the mirrored lane of its
+// 8-lane half, the mirrored lane of its 16-lane row -- applied in that order a commutative/associative combine
+// leaves every lane of the group with the result over all 16 lanes.
+#define DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int group_sum16(int v) {
+  v += dpp_i<DPP_XOR1>(v); v += dpp_i<DPP_XOR2>(v); v += dpp_i<DPP_HALF_MIRROR>(v); v += dpp_i<DPP_ROW_MIRROR>(v);
+  return v;
+}
+// (value, index) -> larger value, smaller index among equal values
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(double& v, int& i) {
+  const double ov = dpp_d<CTRL>(v);
+  const int oi = dpp_i<CTRL>(i);
+  const bool take = ov > v || (ov == v && oi < i);
+  v = take ? ov : v; i = take ? oi : i;
+}
+
 __device__ __forceinline__ double hyp(double a, double b) {
   a = fabs(a); b = fabs(b);
   if (a > b) { b /= a; return a * sqrt(1 + b * b); }
@@ -90,9 +118,9 @@ __device__ void jacobi_group(RansacLds& S, int lane, bool active) {
       else if (gl >= 8 && gl < 8 + N - 1) { const int i = gl - 8 + 1; val = fabs(A0(IC0(i), i)); }
     }
     double mx = val;
-    for (int sft = 8; sft > 0; sft >>= 1) mx = fmax(mx, __shfl_xor(mx, sft));
-    int who = (val == mx) ? gl : 0x7FFFFFFF;
-    for (int sft = 8; sft > 0; sft >>= 1) who = min(who, __shfl_xor(who, sft));
+    int who = gl;              // first maximum in scan order = smallest lane among the equal maxima
+    argmax_step<DPP_XOR1>(mx, who); argmax_step<DPP_XOR2>(mx, who);
+    argmax_step<DPP_HALF_MIRROR>(mx, who); argmax_step<DPP_ROW_MIRROR>(mx, who);
     int k = 0, l = 1;
     double c = 1, sn = 0, t = 0;
     if (!done) {
@@ -127,20 +155,23 @@ __device__ void jacobi_group(RansacLds& S, int lane, bool active) {
       }
     }
     WSYNC();
-    // ---- rescan indR / indC of the two touched indices (four independent scans on four lanes)
-    if (!done && gl < 4) {
-      const int idx = gl < 2 ? k : l;
-      if ((gl & 1) == 0) {
-        if (idx < N - 1) {
-          int m = idx + 1; double mv = fabs(A0(idx, m));
-          for (int i = idx + 2; i < N; i++) { double v2 = fabs(A0(idx, i)); if (mv < v2) mv = v2, m = i; }
-          IR0(idx) = m;
-        }
-      } else if (idx > 0) {
-        int m = 0; double mv = fabs(A0(0, idx));
-        for (int i = 1; i < idx; i++) { double v2 = fabs(A0(i, idx)); if (mv < v2) mv = v2, m = i; }
-        IC0(idx) = m;
+    // ---- rescan indR / indC of the two touched indices: four scans, one per quad of the group (quad 0: row k,
+    //      1: column k, 2: row l, 3: column l); a lane takes elements sl and sl+4 of its scan, the quad combines with
+    //      "larger value, smaller index on ties" = the first maximum of the serial strict-< scan
+    {
+      const int sc = gl >> 2, sl = gl & 3;
+      const int idx = sc < 2 ? k : l;
+      const bool rowscan = (sc & 1) == 0;
+      const bool want = !done && (rowscan ? idx < N - 1 : idx > 0);
+      double mv = -1.0; int m = 0x7FFFFFFF;
+      if (want) {
+        const int first = rowscan ? idx + 1 : 0, end = rowscan ? N : idx;     // elements [first, end)
+        const int i1 = first + sl, i2 = i1 + 4;
+        if (i1 < end) { mv = fabs(rowscan ? A0(idx, i1) : A0(i1, idx)); m = i1; }
+        if (i2 < end) { const double v2 = fabs(rowscan ? A0(idx, i2) : A0(i2, idx)); if (mv < v2) mv = v2, m = i2; }
       }
+      argmax_step<DPP_XOR1>(mv, m); argmax_step<DPP_XOR2>(mv, m);
+      if (want && sl == 0) { if (rowscan) IR0(idx) = m; else IC0(idx) = m; }
     }
     WSYNC();
   }
@@ -657,7 +688,7 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
         good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
       }
     }
-    for (int sft = 8; sft > 0; sft >>= 1) good += __shfl_xor(good, sft);
+    good = group_sum16(good);
     const unsigned long long vmask = __ballot(valid), okmask = __ballot(ok);
     // sequential replay in sample order
     for (int h = 0; h < NG; h++) {
