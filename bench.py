@@ -202,6 +202,23 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(by), "avg_launch_ms": round(stage_ms[dom], 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
+    # the dominant group is VALU-issue-bound, not HBM-bound: say so next to the HBM fraction.  Instruction
+    # count from the committed PMC pass (profiles/valu.json), duration measured live; ceilings measured by
+    # tools/ubench/valu_rate.hip (profiles/r01_valu_issue_rates.txt): 0.96 (3-input / packed / perm forms) .. 1.75
+    # (plain 32-bit add/and) wave-instructions per clock per CU.
+    vpath = os.path.join(ROOT, "profiles", "valu.json")
+    if os.path.exists(vpath) and stage_ms[dom] > 0:
+        try:
+            vj = json.load(open(vpath)).get("%s@%dx%dx%d_n%d_c%d" % (dom, w, h, B, args.nfeatures, args.channels))
+            if vj:
+                props = torch.cuda.get_device_properties(dev)
+                clk = 2.4e9
+                per = vj["valu_wave_insts_per_launch"] / (stage_ms[dom] * 1e-3) / (props.multi_processor_count * clk)
+                roofline["valu_issue"] = {"wave_insts_per_launch": vj["valu_wave_insts_per_launch"],
+                                          "per_clk_per_cu_at_2.4GHz": round(per, 3), "ceiling": [0.96, 1.75],
+                                          "source": vj["source"]}
+        except Exception:
+            pass
     # whole-pipeline view: independent pair = 2*B_frame + B_match + B_out
     pipe_bytes = 2 * sum(per_frame.values()) + sum(per_pair.values())
     roofline["pipeline_bytes_per_pair"] = int(pipe_bytes)

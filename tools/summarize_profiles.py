@@ -91,6 +91,15 @@ if f:
                 k, wc, v["SQ_WAIT_ANY"] / wc, v["SQ_WAIT_INST_ANY"] / wc, v["SQ_ACTIVE_INST_ANY"] / wc,
                 v["SQ_ACTIVE_INST_VALU"] / wc, v["SQ_ACTIVE_INST_LDS"] / wc, v["SQ_WAIT_INST_LDS"] / wc, v["SQ_INSTS_VALU"]))
 
+    # VALU issue of the dominant (FAST) group per launch, for bench.py's informational "valu_issue" entry
+    fast = [k for k in ("k_fast_sample", "k_fast_main", "k_fast_redo", "k_fast") if k in agg]
+    launches = 3.0
+    insts = sum(agg[k]["SQ_INSTS_VALU"] for k in fast) / launches
+    if insts > 0:
+        json.dump({"fast@1280x720x1024_n500_c3": {"valu_wave_insts_per_launch": int(insts),
+                                                  "source": "profiles/%s_pmc_sq.csv (SQ_INSTS_VALU)" % tag}},
+                  open(os.path.join(out, "valu.json"), "w"))
+
 # 4. bench line
 b = os.path.join(src, "bench.json")
 if os.path.exists(b):
