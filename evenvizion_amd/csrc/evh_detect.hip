@@ -304,8 +304,10 @@ __device__ __forceinline__ int fast_score_from_d(const i16 (&d)[16]) {
 struct FastLds {
   uint32_t raw[FR_H * FR_DW];        // 40 x 36 dwords: rows y0-4.., columns x0-8..
   uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
-  uint32_t lst[FT_W * FT_H / 4];     // NMS keeps at most one corner per 2x2 block
-  uint16_t queue[FS_H * FS_DW + 4];  // lifted path: quads with a pixel that passes the pre-test (index | bits << 12)
+  // lst: NMS output, at most one corner per 2x2 block (896 entries).  The lifted path uses the same words first as
+  // its queue of quads with a pixel that passes the pre-test (<= 1020 entries, quad index | pass bits << 16): the
+  // queue is dead before NMS writes the list.
+  uint32_t lst[FS_H * FS_DW + 4];
   uint16_t scored[FT_W * FT_H / 2];  // lifted path: pixels whose exact score reached T
   int lcnt, gbase, qcnt, scnt;
 };
@@ -378,45 +380,65 @@ __device__ __forceinline__ uint32_t pretest_pass4(uint32_t c, uint32_t rd, uint3
 
 // lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
 // compass points), four pixels per 32-bit operation; a quad with at least one passing pixel is queued
-// (quad index | pass bits << 12).  Phase B: exact score of the queued pixels, 4 lanes per queued quad.
+// (quad index | pass bits << 16).  Phase B: exact score of the queued pixels, 4 lanes per queued quad.
 __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, int x0, int y0, int T) {
   const uint32_t K4 = (uint32_t)(T + 1) * 0x01010101u;
   // tiles whose whole score plane lies inside the testable range need no per-pixel range checks (wave-uniform)
   const bool interior = (y0 - 1 >= 3) && (y0 + FT_H < L.h - 3) && (x0 - 4 >= 3) && (x0 + FT_W + 3 < L.w - 3);
-  // (sr, sq) walk the 30 x 34 quad grid without divisions: +256 quads = +7 rows +18 quads
+  // a thread takes quads tid, tid+256, tid+512, tid+768 of the 30 x 34 quad grid; the per-quad pass words (bit 7 of
+  // byte j = pixel j passes) stay in registers and are queued once after the loop with one LDS atomic per wave
+  uint32_t P[4];
   int sr = threadIdx.x / FS_DW, sq = threadIdx.x - sr * FS_DW;
-  for (int i = threadIdx.x; i < FS_H * FS_DW; i += 256) {
-    S.score[i] = 0;                                             // phase B overwrites the bytes that reach T
-    uint32_t colmask = 0xFu;
-    bool rowok = true;
-    if (!interior) {
-      const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
-      rowok = y >= 3 && y < L.h - 3;
-      const int lo = min(max(3 - xq, 0), 4), hi = max(min(L.w - 3 - xq, 4), 0);   // valid pixels j in [lo, hi)
-      colmask = (0xFu << lo) & (0xFu >> (4 - hi)) & 0xFu;
-    }
-    if (rowok && colmask) {
-      const uint32_t* p = S.raw + mad24((uint32_t)(sr + 3), FR_DW, (uint32_t)sq);        // centre row, dword of x = xq-4
-      const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
-      const uint32_t pass = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu,
-                                          __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4);
-      if (pass) {
-        uint32_t pm = ((pass >> 7) & 1u) | ((pass >> 14) & 2u) | ((pass >> 21) & 4u) | ((pass >> 28) & 8u);
-        pm &= colmask;
-        if (pm) S.queue[atomicAdd(&S.qcnt, 1)] = (uint16_t)(i | (pm << 12));
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = threadIdx.x + 256 * k;
+    P[k] = 0;
+    if (i < FS_H * FS_DW) {
+      S.score[i] = 0;                                           // phase B overwrites the bytes that reach T
+      uint32_t cmask = 0x80808080u;
+      bool rowok = true;
+      if (!interior) {
+        const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
+        rowok = y >= 3 && y < L.h - 3;
+        const int lo = min(max(3 - xq, 0), 4), hi = max(min(L.w - 3 - xq, 4), 0);   // valid pixels j in [lo, hi)
+        cmask = lo < hi ? (0x80808080u << (8 * lo)) & (0x80808080u >> (8 * (4 - hi))) : 0u;
+      }
+      if (rowok && cmask) {
+        const uint32_t* p = S.raw + mad24((uint32_t)(sr + 3), FR_DW, (uint32_t)sq);      // centre row, dword of x = xq-4
+        const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
+        P[k] = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu, __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4) &
+               cmask;
       }
     }
-    sr += 7; sq += 18;
+    sr += 7; sq += 18;                                          // +256 quads = +7 rows +18 quads
     if (sq >= FS_DW) { sq -= FS_DW; sr++; }
+  }
+  {
+    const unsigned long long m0 = __ballot(P[0] != 0), m1 = __ballot(P[1] != 0), m2 = __ballot(P[2] != 0),
+                             m3 = __ballot(P[3] != 0);
+    const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), tot = n0 + n1 + n2 + __popcll(m3);
+    if (tot) {                                                  // wave-uniform
+      int base = 0;
+      if ((threadIdx.x & 63) == 0) base = atomicAdd(&S.qcnt, tot);
+      base = __builtin_amdgcn_readfirstlane(base);
+      // entry = quad index | bits {16: px0, 24: px1, 17: px2, 25: px3}
+#define FQ_PUSH(k, off, m)                                                                                              \
+      if (P[k]) S.lst[base + (off) + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32),                             \
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))] =  \
+          (uint32_t)(threadIdx.x + 256 * (k)) | (((P[k] >> 7) | (P[k] >> 22)) << 16)
+      FQ_PUSH(0, 0, m0); FQ_PUSH(1, n0, m1); FQ_PUSH(2, n0 + n1, m2); FQ_PUSH(3, n0 + n1 + n2, m3);
+#undef FQ_PUSH
+    }
   }
   __syncthreads();
   const int nq = S.qcnt;
   const uint8_t* rawb = reinterpret_cast<const uint8_t*>(S.raw);
   uint8_t* scoreb = reinterpret_cast<uint8_t*>(S.score);
   for (int e = threadIdx.x; e < nq * 4; e += 256) {
-    const int ent = S.queue[e >> 2], j = e & 3;
-    if (!((ent >> (12 + j)) & 1)) continue;
-    const int qi = ent & 0xFFF;
+    const uint32_t ent = S.lst[e >> 2];
+    const int j = e & 3;
+    if (!((ent >> (16 + 8 * (j & 1) + (j >> 1))) & 1u)) continue;
+    const int qi = (int)(ent & 0xFFFu);
     const int sr2 = qi / FS_DW, sq2 = qi - sr2 * FS_DW;
     const int pos = sr2 * FQ_PITCH + sq2 * 4 + j;
     const uint8_t* p = rawb + (sr2 + 3) * (FR_DW * 4) + sq2 * 4 + j + 4;
