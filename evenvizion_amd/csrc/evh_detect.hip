@@ -6,6 +6,9 @@
 
 namespace {
 
+__device__ __forceinline__ uint32_t gdot4(uint32_t a, uint32_t b, uint32_t acc) {
+  return __builtin_amdgcn_udot4(a, b, acc, false);
+}
 // 4 gray pixels (n < 4 at the right edge) from `s`: Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14, or a plain copy
 __device__ __forceinline__ uint32_t gray_quad(const uint8_t* __restrict__ s, int channels, int n, int aligned4) {
   uint32_t out = 0;
@@ -14,14 +17,15 @@ __device__ __forceinline__ uint32_t gray_quad(const uint8_t* __restrict__ s, int
     else {
       const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
       const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];           // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-      const uint32_t b0 = w0 & 0xFF, g0 = (w0 >> 8) & 0xFF, r0 = (w0 >> 16) & 0xFF;
-      const uint32_t b1 = w0 >> 24, g1 = w1 & 0xFF, r1 = (w1 >> 8) & 0xFF;
-      const uint32_t b2 = (w1 >> 16) & 0xFF, g2 = w1 >> 24, r2 = w2 & 0xFF;
-      const uint32_t b3 = (w2 >> 8) & 0xFF, g3 = (w2 >> 16) & 0xFF, r3 = w2 >> 24;
-      out = ((b0 * 1868u + g0 * 9617u + r0 * 4899u + 8192u) >> 14) |
-            (((b1 * 1868u + g1 * 9617u + r1 * 4899u + 8192u) >> 14) << 8) |
-            (((b2 * 1868u + g2 * 9617u + r2 * 4899u + 8192u) >> 14) << 16) |
-            (((b3 * 1868u + g3 * 9617u + r3 * 4899u + 8192u) >> 14) << 24);
+      // weights split in bytes (1868 = 7*256 + 76, 9617 = 37*256 + 145, 4899 = 19*256 + 35): two v_dot4_u32_u8 per
+      // pixel on the dword that holds its B,G,R (the fourth byte meets a zero weight); same integers as the scalar form
+      const uint32_t WL = 76u | (145u << 8) | (35u << 16), WH = 7u | (37u << 8) | (19u << 16);
+      const uint32_t p1 = __builtin_amdgcn_alignbyte(w1, w0, 3), p2 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+      const uint32_t y0 = (gdot4(w0, WL, 8192u) + (gdot4(w0, WH, 0u) << 8)) >> 14;
+      const uint32_t y1 = (gdot4(p1, WL, 8192u) + (gdot4(p1, WH, 0u) << 8)) >> 14;
+      const uint32_t y2 = (gdot4(p2, WL, 8192u) + (gdot4(p2, WH, 0u) << 8)) >> 14;
+      const uint32_t y3 = (gdot4(w2, WL << 8, 8192u) + (gdot4(w2, WH << 8, 0u) << 8)) >> 14;
+      out = __builtin_amdgcn_perm(y1, y0, 0x0C0C0400u) | __builtin_amdgcn_perm(y3, y2, 0x04000C0Cu);
     }
   } else if (channels == 1) {
     for (int i = 0; i < n; i++) out |= (uint32_t)s[i] << (8 * i);
@@ -122,16 +126,21 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
     const uint8_t* r0 = tile + yo_s[qy * (PD_H / 8) + rr] * PD_SW;
     const uint8_t* r1 = r0 + PD_SW;
     const int m1 = yc_s[qy * (PD_H / 8) + rr];
-    uint32_t out = 0;
+    // (c0*a + c1*b)*m0 + (c0*a' + c1*b')*m1 + 32768, c0 = 256 - c1, m0 = 256 - m1: 24-bit multiply-adds only (a
+    // multiply-add costs the same issue slot as a shift here); the result byte sits in bits 16..23 of v[i] and two
+    // v_perm_b32 gather the four of them
+    const uint32_t m0 = 256u - (uint32_t)m1;
+    uint32_t v[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int o = xo_s[qx * 4 + i], c1 = xc_s[qx * 4 + i];
-      // c0*a + c1*b with c0 = 256 - c1  ==  256*a + c1*(b - a); likewise for the vertical pass
-      const int a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
-      const int h0 = mad24s(c1, b0 - a0, a0 << 8);
-      const int h1 = mad24s(c1, b1 - a1, a1 << 8);
-      out |= ((uint32_t)(mad24s(m1, h1 - h0, (h0 << 8) + 32768)) >> 16) << (8 * i);
+      const int o = xo_s[qx * 4 + i];
+      const uint32_t c1 = (uint32_t)xc_s[qx * 4 + i], c0 = 256u - c1;
+      const uint32_t a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
+      const uint32_t h0 = mad24(a0, c0, mad24(b0, c1, 0u));
+      const uint32_t h1 = mad24(a1, c0, mad24(b1, c1, 0u));
+      v[i] = mad24(h0, m0, mad24(h1, (uint32_t)m1, 32768u));
     }
+    const uint32_t out = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020C0Cu);
     reinterpret_cast<uint32_t*>(dimg)[mad24((uint32_t)y, (uint32_t)(dst_stride >> 2), (uint32_t)(x >> 2))] = out;
   }
 }
@@ -194,15 +203,18 @@ __global__ __launch_bounds__(256) void k_gray_pyr1(const uint8_t* __restrict__ s
     const uint8_t* r0 = tile + yo_s[qy * (PD_H / 8) + rr] * GP_SW;
     const uint8_t* r1 = r0 + GP_SW;
     const int m1 = yc_s[qy * (PD_H / 8) + rr];
-    uint32_t out = 0;
+    const uint32_t m0 = 256u - (uint32_t)m1;      // same arithmetic as k_pyr_down
+    uint32_t v[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int o = xo_s[qx * 4 + i], c1 = xc_s[qx * 4 + i];
-      const int a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
-      const int h0 = mad24s(c1, b0 - a0, a0 << 8);
-      const int h1 = mad24s(c1, b1 - a1, a1 << 8);
-      out |= ((uint32_t)(mad24s(m1, h1 - h0, (h0 << 8) + 32768)) >> 16) << (8 * i);
+      const int o = xo_s[qx * 4 + i];
+      const uint32_t c1 = (uint32_t)xc_s[qx * 4 + i], c0 = 256u - c1;
+      const uint32_t a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
+      const uint32_t h0 = mad24(a0, c0, mad24(b0, c1, 0u));
+      const uint32_t h1 = mad24(a1, c0, mad24(b1, c1, 0u));
+      v[i] = mad24(h0, m0, mad24(h1, (uint32_t)m1, 32768u));
     }
+    const uint32_t out = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020C0Cu);
     reinterpret_cast<uint32_t*>(dimg)[mad24((uint32_t)y, (uint32_t)(dst_stride >> 2), (uint32_t)(x >> 2))] = out;
   }
 }

@@ -41,6 +41,26 @@ DEF(dot4_u8, "v_dot4_u32_u8 %0, %1, %2, %0")
 DEF(bfe_u32, "v_bfe_u32 %0, %0, %1, %2")
 DEF(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
 DEF(max_i16, "v_max_i16 %0, %0, %1")
+DEF(sub_u32, "v_sub_u32 %0, %0, %1")
+DEF(or_b32, "v_or_b32 %0, %0, %1")
+DEF(xor_b32, "v_xor_b32 %0, %0, %1")
+DEF(lshlrev, "v_lshlrev_b32 %0, 3, %0")
+DEF(lshrrev, "v_lshrrev_b32 %0, 3, %0")
+DEF(bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEF(or3_b32, "v_or3_b32 %0, %0, %1, %2")
+DEF(add3_u32, "v_add3_u32 %0, %0, %1, %2")
+DEF(lshl_add, "v_lshl_add_u32 %0, %0, 2, %1")
+DEF(mul_u24, "v_mul_u32_u24 %0, %0, %1")
+DEF(mul_f32, "v_mul_f32 %0, %0, %1")
+DEF(min_f32, "v_min_f32 %0, %0, %1")
+DEF(cvt_ubyte0, "v_cvt_f32_ubyte0 %0, %0")
+DEF(cvt_u32_f32, "v_cvt_u32_f32 %0, %0")
+DEF(alignbyte, "v_alignbyte_b32 %0, %0, %1, 1")
+DEF(dot2_u16, "v_dot2_u32_u16 %0, %1, %2, %0")
+DEF(max_u16, "v_max_u16 %0, %0, %1")
+DEF(sub_u16, "v_sub_u16 %0, %0, %1")
+DEF(mov_b32, "v_mov_b32 %0, %1")
+DEF(mbcnt_lo, "v_mbcnt_lo_u32_b32 %0, %1, %0")
 
 typedef void (*kern_t)(int*, int);
 struct K { const char* n; kern_t f; };
@@ -54,7 +74,12 @@ int main() {
             {"fma_f32", k_fma_f32}, {"and_b32", k_and_b32}, {"and_or", k_and_or}, {"perm_b32", k_perm_b32},
             {"alignbit", k_alignbit}, {"lshl_or", k_lshl_or}, {"sad_u8", k_sad_u8}, {"med3_i32", k_med3_i32},
             {"min_u16", k_min_u16}, {"mad_u32_u24", k_mad_u32_u24}, {"dot4_u8", k_dot4_u8}, {"bfe_u32", k_bfe_u32},
-            {"cndmask", k_cndmask}, {"max_i16", k_max_i16}};
+            {"cndmask", k_cndmask}, {"max_i16", k_max_i16}, {"sub_u32", k_sub_u32}, {"or_b32", k_or_b32},
+            {"xor_b32", k_xor_b32}, {"lshlrev", k_lshlrev}, {"lshrrev", k_lshrrev}, {"bitop3", k_bitop3},
+            {"or3_b32", k_or3_b32}, {"add3_u32", k_add3_u32}, {"lshl_add", k_lshl_add}, {"mul_u24", k_mul_u24},
+            {"mul_f32", k_mul_f32}, {"min_f32", k_min_f32}, {"cvt_ubyte0", k_cvt_ubyte0}, {"cvt_u32_f32", k_cvt_u32_f32},
+            {"alignbyte", k_alignbyte}, {"dot2_u16", k_dot2_u16}, {"max_u16", k_max_u16}, {"sub_u16", k_sub_u16},
+            {"mov_b32", k_mov_b32}, {"mbcnt_lo", k_mbcnt_lo}};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (auto& k : ks) {
     hipLaunchKernelGGL(k.f, dim3(blocks), dim3(256), 0, 0, out, 1);
