@@ -370,24 +370,33 @@ __device__ __forceinline__ void fast_dense_scores(FastLds& S, const EvhLevel& L,
 // centre - ring > T for two adjacent compass points (D), or ring - centre > T for two adjacent ones (B).
 // Adjacent pairs of a 4-cycle: (D0&D4)|(D4&D8)|(D8&D12)|(D12&D0) == (D0|D8)&(D4|D12).  K4 = (T+1) * 0x01010101, T+1 <= 127.
 // swar_ge: bit 7 of every byte = (a >= b), from the 7-bit difference t = (a|H) - (b&~H) which never borrows.
+// Three-input boolean ops are spelled as v_bitop3_b32 explicitly: it issues at the full VALU rate on gfx950 while
+// v_or3 / v_and_or (what the compiler picks for the same expressions) issue at half rate
+// (profiles/r01_valu_issue_rates.txt).  Truth table = the expression evaluated on (0xF0, 0xCC, 0xAA).
+template <class F>
+constexpr uint32_t tt3(F f) { return f(0xF0u, 0xCCu, 0xAAu) & 0xFFu; }
+#define BITOP3(a, b, c, EXPR) \
+  __builtin_amdgcn_bitop3_b32((a), (b), (c), tt3([](uint32_t A, uint32_t B, uint32_t C) { return (EXPR); }))
 __device__ __forceinline__ uint32_t swar_ge(uint32_t aH, uint32_t a, uint32_t b, uint32_t bL) {
   const uint32_t t = aH - bL;
-  return (a & ~b) | (~(a ^ b) & t);
+  return BITOP3(a, b, t, (A & ~B) | (~(A ^ B) & C));
 }
 __device__ __forceinline__ uint32_t pretest_pass4(uint32_t c, uint32_t rd, uint32_t rr, uint32_t ru, uint32_t rl, uint32_t K4) {
   const uint32_t H = 0x80808080u, Lm = 0x7F7F7F7Fu;
-  const uint32_t t = (c | H) - K4;     // 128 + (c & 127) - K per byte
-  const uint32_t cl = t & (c | Lm);    // c - K where c >= K
-  const uint32_t vD = c | t;           // bit 7: c >= K
-  const uint32_t u = (c & Lm) + K4;    // (c & 127) + K <= 254 per byte
-  const uint32_t ch = u | (c & H);     // c + K where it fits a byte
-  const uint32_t vB = ~(c & u);        // bit 7: c + K <= 255
+  const uint32_t t = (c | H) - K4;                          // 128 + (c & 127) - K per byte
+  const uint32_t cl = BITOP3(t, c, Lm, A & (B | C));        // c - K where c >= K;          bit 7 of (c | t): c >= K
+  const uint32_t u = (c & Lm) + K4;                         // (c & 127) + K <= 254 per byte
+  const uint32_t ch = BITOP3(u, c, H, A | (B & C));         // c + K where it fits a byte;  bit 7 of ~(c & u): it does
   const uint32_t clH = cl | H, chL = ch & Lm;
   const uint32_t D0 = swar_ge(clH, cl, rd, rd & Lm), D4 = swar_ge(clH, cl, rr, rr & Lm);
   const uint32_t D8 = swar_ge(clH, cl, ru, ru & Lm), D12 = swar_ge(clH, cl, rl, rl & Lm);
   const uint32_t B0 = swar_ge(rd | H, rd, ch, chL), B4 = swar_ge(rr | H, rr, ch, chL);
   const uint32_t B8 = swar_ge(ru | H, ru, ch, chL), B12 = swar_ge(rl | H, rl, ch, chL);
-  return (((D0 | D8) & (D4 | D12) & vD) | ((B0 | B8) & (B4 | B12) & vB)) & H;
+  const uint32_t Dx = D0 | D8, Bx = B0 | B8;
+  const uint32_t Dy = BITOP3(D4, D12, Dx, (A | B) & C), By = BITOP3(B4, B12, Bx, (A | B) & C);
+  const uint32_t Dm = BITOP3(Dy, c, t, A & (B | C));        // & (c >= K)
+  const uint32_t Bm = BITOP3(By, c, u, A & ~(B & C));       // & (c + K <= 255)
+  return BITOP3(Dm, Bm, H, (A | B) & C);
 }
 
 // lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
