@@ -52,6 +52,7 @@ SIGNATURES = {
     "evh_static_filter": (_i, [_vp, _vp, _vp, _i, _vp, _pi]),
     "evh_pair_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp]),
     "evh_stream_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
+    "evh_multi_stream_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "evh_stream_static_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _i, _vp, _vp]),
     "evh_stream_scan": (_i, [_vp, _vp, _i, _vp, _vp, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "evh_pair_from_slots": (_i, [_vp, _i, _i, _vp, _vp, _pi]),
@@ -270,6 +271,17 @@ class Context:
         self._check(self.lib.evh_stream_homography_batch(
             self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures, float(thr), int(max_iters), float(conf),
             int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,
+            state_out.data_ptr() if state_out is not None else None, out_H.data_ptr(), out_status.data_ptr()))
+
+    def multi_stream_homography_batch(self, frames, out_H, out_status, state_in=None, state_out=None, nfeatures=500,
+                                      thr=3.0, max_iters=2000, conf=0.995, force_max_iters=False):
+        """frames: CUDA uint8 [S,F,h,w(,3)] -- S independent streams of F consecutive frames each; out_H f64[S,F-1,9],
+        out_status i32[S,F-1]; state_in / state_out f64[S,18] carry {H_sup, H_prev} of every stream between calls."""
+        S, F, h, w = frames.shape[:4]
+        cn = 1 if frames.dim() == 4 else frames.shape[4]
+        self._check(self.lib.evh_multi_stream_homography_batch(
+            self.h, frames.data_ptr(), S, F, w, h, cn, w * cn, w * h * cn, nfeatures, float(thr), int(max_iters),
+            float(conf), int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,
             state_out.data_ptr() if state_out is not None else None, out_H.data_ptr(), out_status.data_ptr()))
 
     def _torch_stream(self):

@@ -175,7 +175,7 @@ int join_solve(evh_ctx* c) {
 }
 
 // RANSAC #1 + static filter, then compute_homography, on the solve stream when asynchronous solve is enabled
-int solve_pairs(evh_ctx* c, EvhRansacArgs R, int npairs, int stream_mode) {
+int solve_pairs(evh_ctx* c, EvhRansacArgs R, int npairs, int nstreams = 0, int pairs_per_stream = 0, int pitch = 0) {
   hipStream_t main = c->stream;
   const bool async = c->async_solve && c->solve_stream;
   if (async) {
@@ -185,7 +185,10 @@ int solve_pairs(evh_ctx* c, EvhRansacArgs R, int npairs, int stream_mode) {
   }
   int rc;
   { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC, c->stream); rc = evh_launch_ransac_static(c, R, npairs); }
-  if (!rc) { EvhProfScope ps(c, EVH_ST_RANSAC_FINAL, c->stream); rc = evh_launch_ransac_final(c, R, npairs, stream_mode); }
+  if (!rc) {
+    EvhProfScope ps(c, EVH_ST_RANSAC_FINAL, c->stream);
+    rc = evh_launch_ransac_final(c, R, nstreams > 0 ? pairs_per_stream : npairs, nstreams, pitch);
+  }
   if (async) {
     hipError_t e = hipEventRecord(c->ev_solve_done, c->solve_stream);
     c->stream = main;
@@ -575,7 +578,7 @@ int evh_pair_homography_batch(evh_ctx* c, const uint8_t* d_frames, int npairs, i
   if (rc) return rc;
   EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
   R.H = d_H; R.out_status = d_status;
-  return solve_pairs(c, R, npairs, mode == EVH_MODE_STREAM);
+  return solve_pairs(c, R, npairs, mode == EVH_MODE_STREAM ? 1 : 0, npairs, npairs);
 }
 
 int evh_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
@@ -592,7 +595,7 @@ int evh_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nframes
   R.H = d_H; R.out_status = d_status;
   if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
   R.state_out = d_state_out;
-  return solve_pairs(c, R, npairs, 1);
+  return solve_pairs(c, R, npairs, 1, npairs, npairs);
 }
 
 int evh_match_static_from_slots(evh_ctx* c, int cur_slot, int prev_slot, float* h_pts, int cap, int* h_count, int* h_status) {
@@ -632,12 +635,32 @@ int evh_compute_homography(evh_ctx* c, const float* h_pts, int n, const double* 
   }
   // the stream kernel with one pair applies the optional pre-transform; Hprev0 = Hsup0 only marks "not first"
   R.Hprev0 = R.Hsup0;
-  int rc = evh_launch_ransac_final(c, R, 1, h_Hsup ? 1 : 0);
+  int rc = evh_launch_ransac_final(c, R, 1, h_Hsup ? 1 : 0, 1);
   if (rc) return rc;
   EVH_HIP(c, hipStreamSynchronize(c->stream));
   EVH_HIP(c, hipMemcpy(h_H, c->d_small, 9 * sizeof(double), hipMemcpyDeviceToHost));
   EVH_HIP(c, hipMemcpy(h_status, c->d_small + 32, sizeof(int), hipMemcpyDeviceToHost));
   return EVH_SUCCESS;
+}
+
+int evh_multi_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nstreams, int frames_per_stream, int w,
+                                      int h, int channels, int64_t row_stride, int64_t frame_stride, int nfeatures,
+                                      double ransac_thr, int ransac_max_iters, double ransac_conf, int force_max_iters,
+                                      const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status) {
+  if (!c || !d_frames || !d_H || !d_status || nstreams < 1 || frames_per_stream < 2)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_multi_stream_homography_batch: bad argument");
+  const int64_t nframes64 = (int64_t)nstreams * frames_per_stream;
+  if (nframes64 > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "batch needs more frame slots than max_frames");
+  const int nframes = (int)nframes64;
+  int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
+  if (rc) return rc;
+  // pair slot p = (frame p + 1, frame p): the slot that straddles two streams is computed and never read
+  if ((rc = match_pairs(c, nframes - 1, 1, 1, 0, 1))) return rc;
+  EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
+  R.H = d_H; R.out_status = d_status;
+  if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
+  R.state_out = d_state_out;
+  return solve_pairs(c, R, nframes - 1, nstreams, frames_per_stream - 1, frames_per_stream);
 }
 
 int evh_stream_static_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
@@ -676,7 +699,7 @@ int evh_stream_scan(evh_ctx* c, const float* d_rows, int row_cap, const int32_t*
   if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
   R.state_out = d_state_out;
   int rc;
-  { EvhProfScope ps(c, EVH_ST_RANSAC_FINAL); rc = evh_launch_ransac_final(c, R, npairs, 1); }
+  { EvhProfScope ps(c, EVH_ST_RANSAC_FINAL); rc = evh_launch_ransac_final(c, R, npairs, 1, npairs); }
   return rc;
 }
 
@@ -693,7 +716,7 @@ int evh_pair_from_slots(evh_ctx* c, int cur_slot, int prev_slot, const double* h
     EVH_HIP(c, hipMemcpyAsync(c->d_small + 16, h_Hsup, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     R.Hsup0 = c->d_small + 16; R.Hprev0 = R.Hsup0;
   }
-  rc = evh_launch_ransac_final(c, R, 1, h_Hsup ? 1 : 0);
+  rc = evh_launch_ransac_final(c, R, 1, h_Hsup ? 1 : 0, 1);
   if (rc) return rc;
   EVH_HIP(c, hipStreamSynchronize(c->stream));
   EVH_HIP(c, hipMemcpy(h_H, c->d_small, 9 * sizeof(double), hipMemcpyDeviceToHost));

@@ -32,4 +32,4 @@ int evh_launch_find_homography(evh_ctx* c, const EvhRansacArgs& A);
 int evh_launch_static_filter(evh_ctx* c, const double* d_H, const float* d_rows, int n, int* d_rbin, float* d_out,
                              int* d_count);
 int evh_launch_ransac_static(evh_ctx* c, const EvhRansacArgs& A, int npairs);
-int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A, int npairs, int stream_mode);
+int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A, int npairs, int nstreams, int pitch);

@@ -897,37 +897,45 @@ __global__ __launch_bounds__(64) void k_ransac_final_pairs(EvhRansacArgs A) {
 
 // phase 2, stream semantics (video_processing.py:83-105): sequential scan over the pairs of one stream with the
 // running superposition; a failed pair repeats the previous H (none_H_processing=True).
-__global__ __launch_bounds__(64) void k_ransac_final_stream(EvhRansacArgs A, int npairs) {
+__global__ __launch_bounds__(64) void k_ransac_final_stream(EvhRansacArgs A, int npairs, int pitch) {
+  // one wavefront per stream: block s scans the npairs pairs whose per-pair slots start at s * pitch (several streams
+  // of one batch sit `pitch` pair slots apart); H / status are written compactly at s * npairs + p
   RansacLds& S = g_lds;
   __shared__ double Hsup[9], Hprev[9], Hcur[9];
   __shared__ int have_prev;
-  const int lane = threadIdx.x;
-  if (lane == 0) have_prev = A.Hprev0 ? 1 : 0;
-  if (lane < 9 && A.Hsup0) Hsup[lane] = A.Hsup0[lane];
-  if (lane < 9 && A.Hprev0) Hprev[lane] = A.Hprev0[lane];
+  const int lane = threadIdx.x, s = blockIdx.x;
+  const double* Hsup0 = A.Hsup0 ? A.Hsup0 + 18 * s : nullptr;
+  const double* Hprev0 = A.Hprev0 ? A.Hprev0 + 18 * s : nullptr;
+  const int64_t slot0 = (int64_t)s * pitch;                 // first pair slot of this stream; also its scratch slot
+  double* Hout = A.H + (int64_t)9 * s * npairs;
+  int* stout = A.out_status + (int64_t)s * npairs;
+  if (lane == 0) have_prev = Hprev0 ? 1 : 0;
+  if (lane < 9 && Hsup0) Hsup[lane] = Hsup0[lane];
+  if (lane < 9 && Hprev0) Hprev[lane] = Hprev0[lane];
   WSYNC();
-  bool first = A.Hsup0 == nullptr;
+  bool first = Hsup0 == nullptr;
   for (int p = 0; p < npairs; p++) {
-    int st = A.status[p];
+    int st = A.status[slot0 + p];
     if (st == EVH_PAIR_OK) {
-      const int n = A.npts2[p];
-      const float* rows = A.pts2 + (int64_t)p * A.row_stride * 4;
-      // the scan is sequential: one pair's worth of scratch (slot 0) serves any number of pairs
-      st = compute_homography_wave(S, lane, rows, n, first ? nullptr : Hsup, A, A.mask, A.pts, A.crow, A.lm,
-                                   A.info ? A.info + 8 * p + 4 : nullptr);
+      const int n = A.npts2[slot0 + p];
+      const float* rows = A.pts2 + (slot0 + p) * A.row_stride * 4;
+      // the scan is sequential: one pair's worth of scratch (the stream's first slot) serves all its pairs
+      st = compute_homography_wave(S, lane, rows, n, first ? nullptr : Hsup, A, A.mask + slot0 * A.row_stride,
+                                   A.pts + slot0 * A.row_stride * 4, A.crow + slot0 * A.row_stride * 4,
+                                   A.lm + slot0 * A.row_stride * 4, A.info ? A.info + 8 * (slot0 + p) + 4 : nullptr);
     }
     WSYNC();
-    if (lane == 0) A.out_status[p] = st;
+    if (lane == 0) stout[p] = st;
     if (st != EVH_PAIR_OK && !have_prev) {
       // the reference raises here (None.tolist()); mark the pair and stop the scan
-      if (lane < 9) A.H[9 * p + lane] = __longlong_as_double(0x7FF8000000000000ll);
-      for (int q = p + 1 + lane; q < npairs; q += NL) { A.out_status[q] = st; }
-      for (int q = p + 1; q < npairs; q++) if (lane < 9) A.H[9 * q + lane] = __longlong_as_double(0x7FF8000000000000ll);
+      if (lane < 9) Hout[9 * p + lane] = __longlong_as_double(0x7FF8000000000000ll);
+      for (int q = p + 1 + lane; q < npairs; q += NL) { stout[q] = st; }
+      for (int q = p + 1; q < npairs; q++) if (lane < 9) Hout[9 * q + lane] = __longlong_as_double(0x7FF8000000000000ll);
       return;
     }
     if (lane < 9) Hcur[lane] = st == EVH_PAIR_OK ? S.H[lane] : Hprev[lane];
     WSYNC();
-    if (lane < 9) { A.H[9 * p + lane] = Hcur[lane]; Hprev[lane] = Hcur[lane]; }
+    if (lane < 9) { Hout[9 * p + lane] = Hcur[lane]; Hprev[lane] = Hcur[lane]; }
     // matrix_superposition (utils.py:139-145); np.dot(3x3,3x3) = forward FMA chain (pinned by fixtures)
     double P = 0;
     if (!first && lane < 9) {
@@ -941,7 +949,7 @@ __global__ __launch_bounds__(64) void k_ransac_final_stream(EvhRansacArgs A, int
     first = false;
     WSYNC();
   }
-  if (A.state_out && lane < 9) { A.state_out[lane] = Hsup[lane]; A.state_out[9 + lane] = Hprev[lane]; }
+  if (A.state_out && lane < 9) { A.state_out[18 * s + lane] = Hsup[lane]; A.state_out[18 * s + 9 + lane] = Hprev[lane]; }
 }
 
 }  // namespace
@@ -963,9 +971,10 @@ int evh_launch_ransac_static(evh_ctx* c, const EvhRansacArgs& A, int npairs) {
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
-int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A, int npairs, int stream_mode) {
+int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A, int npairs, int nstreams, int pitch) {
   if (npairs <= 0) return EVH_SUCCESS;
-  if (stream_mode) hipLaunchKernelGGL(k_ransac_final_stream, dim3(1), dim3(64), 0, c->stream, A, npairs);
+  // nstreams == 0: independent pairs; otherwise nstreams sequential scans of npairs pairs each, `pitch` pair slots apart
+  if (nstreams > 0) hipLaunchKernelGGL(k_ransac_final_stream, dim3(nstreams), dim3(64), 0, c->stream, A, npairs, pitch);
   else hipLaunchKernelGGL(k_ransac_final_pairs, dim3(npairs), dim3(64), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;

@@ -163,6 +163,17 @@ int evh_stream_homography_batch(evh_ctx* ctx, const uint8_t* d_frames, int nfram
                                 int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
                                 int ransac_max_iters, double ransac_conf, int force_max_iters,
                                 const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status);
+/* Several independent streams in one batch: d_frames holds nstreams x frames_per_stream frames, stream-major
+ * (all frames of stream 0, then stream 1, ...).  Everything up to the static filter runs over all frames / pairs
+ * at once; the sequential scans of the streams then run concurrently, one wavefront per stream, each with its own
+ * {H_sup, H_prev}: d_state_in / d_state_out f64[nstreams][18] (d_state_in NULL = every stream starts here).
+ * d_H f64[nstreams][frames_per_stream-1][9], d_status i32[nstreams][frames_per_stream-1].  Per stream the results
+ * are bit-identical to evh_stream_homography_batch on that stream alone.  Does not synchronise.                 */
+int evh_multi_stream_homography_batch(evh_ctx* ctx, const uint8_t* d_frames, int nstreams, int frames_per_stream,
+                                      int w, int h, int channels, int64_t row_stride, int64_t frame_stride,
+                                      int nfeatures, double ransac_thr, int ransac_max_iters, double ransac_conf,
+                                      int force_max_iters, const double* d_state_in, double* d_state_out,
+                                      double* d_H, int32_t* d_status);
 /* Two-phase form of the stream path, for sharding ONE stream over several GPUs with the reference's semantics
  * (video_processing.py:67-105).  Phase 1 is independent per pair and runs wherever the frames are:
  * detect, match, ratio/unique filter, RANSAC #1, static filter (frame_processing.py:91-98, matching.py:131-163) on

@@ -394,6 +394,47 @@ def test_two_phase_stream_equals_whole_stream(ctx):
     assert np.allclose(H.cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
 
 
+def test_multi_stream_batch_equals_each_stream_alone():
+    """evh_multi_stream_homography_batch: S streams scanned concurrently (one wavefront each) == each stream through
+    evh_stream_homography_batch on its own, bit for bit, including carried state and a stream with a failing pair."""
+    from evenvizion_amd._lib import Context
+    w, h, S_, F = 400, 224, 3, 5
+    streams = [S.make_stream(40 + i, 2 * F - 1, w, h)[0] for i in range(S_)]
+    streams[1][2] = 128                                   # a flat frame inside stream 1: two failing pairs
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=S_ * F)
+    try:
+        # reference: every stream alone, in two chunks (F frames, then F frames overlapping by one) with carried state
+        ref_H, ref_st = [], []
+        for fr in streams:
+            Hs, sts = [], []
+            state = torch.zeros(18, dtype=torch.float64, device="cuda")
+            for k, chunk in enumerate((fr[:F], fr[F - 1:])):
+                H = torch.zeros(F - 1, 9, dtype=torch.float64, device="cuda")
+                st = torch.full((F - 1,), -1, dtype=torch.int32, device="cuda")
+                c.stream_homography_batch(dev(chunk), H, st, state_in=state if k else None, state_out=state)
+                c.synchronize()
+                Hs.append(H.clone()); sts.append(st.clone())
+            ref_H.append(torch.cat(Hs)); ref_st.append(torch.cat(sts))
+        # all streams at once, same two chunks
+        state = torch.zeros(S_, 18, dtype=torch.float64, device="cuda")
+        got_H, got_st = [], []
+        for k in range(2):
+            batch = np.stack([fr[:F] if k == 0 else fr[F - 1:] for fr in streams])
+            H = torch.zeros(S_, F - 1, 9, dtype=torch.float64, device="cuda")
+            st = torch.full((S_, F - 1), -1, dtype=torch.int32, device="cuda")
+            d = dev(batch)
+            c.multi_stream_homography_batch(d, H, st, state_in=state if k else None, state_out=state)
+            c.synchronize()
+            got_H.append(H.clone()); got_st.append(st.clone())
+        for i in range(S_):
+            Hi = torch.cat([got_H[0][i], got_H[1][i]]); sti = torch.cat([got_st[0][i], got_st[1][i]])
+            assert torch.equal(sti, ref_st[i]), (i, sti, ref_st[i])
+            assert torch.equal(Hi, ref_H[i])
+        assert int((ref_st[1] != 0).sum()) == 2 and int((ref_st[0] != 0).sum()) == 0
+    finally:
+        c.close()
+
+
 def test_resize_area(ctx):
     rng = np.random.default_rng(4)
     for (sw, sh, width, cn) in [(1170, 658, 400, 3), (1280, 720, 320, 3), (800, 600, 400, 1), (900, 300, 300, 3),
