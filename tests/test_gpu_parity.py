@@ -543,3 +543,29 @@ def test_heatmap_extent_reproduces_reference_metrics_file():
     got = field.cpu().numpy()[0]
     assert np.array_equal(got[..., 0], u) and np.array_equal(got[..., 1], v)
     runtime.reset()
+
+
+def test_component_cli_outputs(tmp_path, monkeypatch):
+    """evenvizion_amd.component: the argument surface and the non-visual outputs of evenvizion_component.py:101-140
+    (dict_with_homography_matrix.json, metrics_file.txt) + fixed_coordinates.json, on a synthetic stream."""
+    import json
+    from evenvizion_amd import component, heatmap
+    from evenvizion_amd.processing.utils import read_homography_dict, superposition_dict
+    monkeypatch.chdir(tmp_path)
+    n = 7
+    coords = {str(k): [{"x1": 100.5 + k, "y1": 80.25}, {"x1": 300.0, "y1": 150.0 - k}] for k in range(1, n + 1)}
+    (tmp_path / "coords.json").write_text(json.dumps(coords))
+    folder = component.main(["--path_to_video", "synthetic:%d:640x360:3" % n, "--experiment_name", "exp",
+                             "--resize_width", "400", "--path_to_original_coordinate", str(tmp_path / "coords.json")])
+    assert folder == str(tmp_path / "exp" / ("synthetic_%d_640x360_3" % n))
+    d = json.load(open(folder + "/dict_with_homography_matrix.json"))
+    assert list(d.keys()) == [str(k) for k in range(2, n + 1)] + ["resize_info"]        # keys start at 2, resize_info last
+    assert d["resize_info"] == {"h": 225, "w": 400}                                        # int(360 * 400 / 640)
+    assert all(np.asarray(d[str(k)]["H"]).shape == (3, 3) for k in range(2, n + 1))
+    Hs, ri = read_homography_dict(folder + "/dict_with_homography_matrix.json")
+    txt = open(folder + "/metrics_file.txt").read()
+    assert txt == "Maximum movement during the entire video: {}".format(heatmap.max_movement(superposition_dict(Hs), ri))
+    fixed = json.load(open(folder + "/fixed_coordinates.json"))
+    assert set(fixed.keys()) == set(coords.keys()) and len(fixed["3"]) == 2 and set(fixed["3"][0]) == {"x1", "y1"}
+    with pytest.raises(NotImplementedError):
+        component.main(["--show_matching_visualization", "True"])
