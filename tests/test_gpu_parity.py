@@ -569,3 +569,39 @@ def test_component_cli_outputs(tmp_path, monkeypatch):
     assert set(fixed.keys()) == set(coords.keys()) and len(fixed["3"]) == 2 and set(fixed["3"][0]) == {"x1", "y1"}
     with pytest.raises(NotImplementedError):
         component.main(["--show_matching_visualization", "True"])
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (70, 90), (97, 131), (129, 257), (255, 255), (1000, 70), (1023, 577)])
+def test_odd_and_small_sizes_full_path(w, h):
+    """Ragged geometry: widths that are not multiples of 4, levels smaller than the 31-px border (no key points at
+    all -> status 1), single-tile levels, very wide/flat frames; synthetic texture and white noise.  Key points,
+    descriptors, statuses and H must equal the oracle's."""
+    from evenvizion_amd._lib import Context
+    rng = np.random.default_rng(w * 7919 + h)
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=2)
+    try:
+        for kind in ("synth", "noise"):
+            if kind == "synth":
+                a, b, _ = S.make_pair(int(rng.integers(1, 1000)), w, h)
+            else:
+                a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+                b = np.roll(a, 3, axis=1)
+            fr = np.stack([a, b])
+            H = torch.zeros(1, 9, dtype=torch.float64, device="cuda")
+            st = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+            c.pair_homography_batch(dev(fr), 1, 0, H, st)
+            c.synchronize()
+            for f in range(2):
+                o = O.orb_detect(fr[f])
+                g = c.orb_download(f) if len(o["xy"]) else None
+                if g is None:
+                    assert c.lib.evh_orb_count(c.h, f) == 0
+                else:
+                    assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"])
+                    assert np.array_equal(g["octave"], o["octave"])
+            Ho, so = O.pairs_gray_batch(fr)
+            assert st.cpu().numpy()[0] == so[0]
+            if so[0] == 0:
+                assert np.allclose(H.cpu().numpy().reshape(3, 3), Ho[0], rtol=1e-9, atol=1e-12)
+    finally:
+        c.close()
