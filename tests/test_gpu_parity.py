@@ -605,3 +605,44 @@ def test_odd_and_small_sizes_full_path(w, h):
                 assert np.allclose(H.cpu().numpy().reshape(3, 3), Ho[0], rtol=1e-9, atol=1e-12)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("cn", [1, 3])
+def test_unaligned_and_padded_input_layout(ctx, cn):
+    """Frames handed over with an odd base address, padded rows and padded frames take the byte-wise gray path and
+    the unfused level-1 kernel; every pyramid level and the key points must still equal the oracle's."""
+    w, h = 333, 217
+    a, b, _ = S.make_pair(5, w, h)
+    gray = np.stack([a, b])
+    src = gray if cn == 1 else S.gray_to_bgr(gray)
+    row_stride = w * cn + 5
+    frame_stride = row_stride * h + 3
+    buf = np.zeros(1 + 2 * frame_stride + 64, np.uint8)
+    for f in range(2):
+        for y in range(h):
+            o = 1 + f * frame_stride + y * row_stride
+            buf[o:o + w * cn] = src[f, y].reshape(-1)
+    d = dev(buf)
+    ctx._check(ctx.lib.evh_orb_detect_batch(ctx.h, d.data_ptr() + 1, 2, w, h, cn, row_stride, frame_stride, 500))
+    ctx.synchronize()
+    for f in range(2):
+        want = O.orb_pyramid(gray[f])
+        for l in range(8):
+            assert np.array_equal(ctx.download_level(f, l), want[l]), "level %d" % l
+        o = O.orb_detect(gray[f]); g = ctx.orb_download(f)
+        assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"])
+    # aligned base but padded rows (stride multiple of 4): the fused path with a non-tight layout
+    row_stride = (w * cn + 7) // 4 * 4
+    frame_stride = row_stride * h + 8
+    buf = np.zeros(2 * frame_stride + 64, np.uint8)
+    for f in range(2):
+        for y in range(h):
+            o = f * frame_stride + y * row_stride
+            buf[o:o + w * cn] = src[f, y].reshape(-1)
+    d = dev(buf)
+    ctx._check(ctx.lib.evh_orb_detect_batch(ctx.h, d.data_ptr(), 2, w, h, cn, row_stride, frame_stride, 500))
+    ctx.synchronize()
+    for f in range(2):
+        want = O.orb_pyramid(gray[f])
+        for l in range(8):
+            assert np.array_equal(ctx.download_level(f, l), want[l]), "level %d" % l
