@@ -1014,10 +1014,18 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
       s0 += I; s1 += u * I;
     }
     m10 = s1; m01 = v * s0;
+    // horizontal 7-tap pass as byte dot products: X(c) = the dword of bytes c..c+3 of the realigned row (every fourth
+    // one is a register as it stands, the others one v_alignbyte), h(c) = dot4(X(c), {18,34,49,55}) +
+    // dot4(X(c+4), {49,34,18,0}) -- the same integer as gauss7 on the seven bytes
     uint16_t* hrow = hbuf[wv] + lane * DH_STRIDE;
+    uint32_t X[DB_N + 4];
+#pragma unroll
+    for (int c = 0; c < DB_N + 4; c++)
+      X[c] = (c & 3) == 0 ? w[c >> 2] : __builtin_amdgcn_alignbyte(w[(c >> 2) + 1], w[c >> 2], (uint32_t)(c & 3));
+    const uint32_t W0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), W1 = 49u | (34u << 8) | (18u << 16);
 #pragma unroll
     for (int c = 0; c < DB_N; c++)
-      hrow[c] = (uint16_t)gauss7(RB(c), RB(c + 1), RB(c + 2), RB(c + 3), RB(c + 4), RB(c + 5), RB(c + 6));
+      hrow[c] = (uint16_t)__builtin_amdgcn_udot4(X[c + 4], W1, __builtin_amdgcn_udot4(X[c], W0, 0u, false), false);
 #undef RB
   }
   for (int s = 32; s > 0; s >>= 1) { m10 += __shfl_xor(m10, s); m01 += __shfl_xor(m01, s); }
