@@ -900,7 +900,24 @@ struct DescribeArgs {
 __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// byte masks of the radius-15 disc: c_omask[|v|][d] selects the bytes c = 4d..4d+3 of patch row v with |c - 22| <= umax[|v|]
+__constant__ uint32_t c_omask[16][10] = {
+  {0x00000000u, 0xFF000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x0000FFFFu},
+  {0x00000000u, 0xFF000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x0000FFFFu},
+  {0x00000000u, 0xFF000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x0000FFFFu},
+  {0x00000000u, 0xFF000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x0000FFFFu},
+  {0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x000000FFu},
+  {0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x000000FFu},
+  {0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x000000FFu},
+  {0x00000000u, 0x00000000u, 0xFFFFFF00u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0xFFFFFF00u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0xFFFF0000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00FFFFFFu, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0xFF000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x0000FFFFu, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x000000FFu, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0x00000000u, 0xFFFFFF00u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0x00000000u, 0xFFFF0000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00FFFFFFu, 0x00000000u, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x000000FFu, 0x00000000u, 0x00000000u},
+  {0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0xFF000000u, 0xFFFFFFFFu, 0x0000FFFFu, 0x00000000u, 0x00000000u, 0x00000000u}};
 
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -1003,15 +1020,24 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
     uint32_t w[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) w[j] = __builtin_amdgcn_alignbyte(rp[j + 1], rp[j], sh);
-#define RB(c) ((int)((w[(c) >> 2] >> (8 * ((c) & 3))) & 0xFFu))
     const int v = lane - DP_R;
-    const int um = abs(v) <= 15 ? c_umax[abs(v)] : -1;   // rows outside the disc contribute nothing
+    // intensity-centroid moments over the disc as byte dot products: row bytes masked by the disc's extent in this
+    // row, s0 = sum I, s1 = sum (u + 15) I - 15 s0 with u = c - 22 (weights 0..30 fit a byte); same integers as the
+    // per-pixel sums
     int s0 = 0, s1 = 0;
+    if (abs(v) <= 15) {
+      const uint32_t* mk = c_omask[abs(v)];
+      uint32_t a0 = 0, a1 = 0;
 #pragma unroll
-    for (int c = DP_R - 15; c <= DP_R + 15; c++) {
-      const int u = c - DP_R;
-      const int I = abs(u) <= um ? RB(c) : 0;
-      s0 += I; s1 += u * I;
+      for (int d = 1; d <= 9; d++) {               // bytes 4 .. 39 cover c = 7 .. 37
+        const uint32_t x = w[d] & mk[d];
+        const int u0 = 4 * d - DP_R + 15;          // weight of the dword's first byte; bytes outside 0..30 are masked off
+        const uint32_t wt = ((uint32_t)(u0 & 0xFF)) | ((uint32_t)((u0 + 1) & 0xFF) << 8) | ((uint32_t)((u0 + 2) & 0xFF) << 16) |
+                            ((uint32_t)((u0 + 3) & 0xFF) << 24);
+        a0 = __builtin_amdgcn_udot4(x, 0x01010101u, a0, false);
+        a1 = __builtin_amdgcn_udot4(x, wt, a1, false);
+      }
+      s0 = (int)a0; s1 = (int)a1 - 15 * (int)a0;
     }
     m10 = s1; m01 = v * s0;
     // horizontal 7-tap pass as byte dot products: X(c) = the dword of bytes c..c+3 of the realigned row (every fourth
@@ -1026,7 +1052,6 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
 #pragma unroll
     for (int c = 0; c < DB_N; c++)
       hrow[c] = (uint16_t)__builtin_amdgcn_udot4(X[c + 4], W1, __builtin_amdgcn_udot4(X[c], W0, 0u, false), false);
-#undef RB
   }
   for (int s = 32; s > 0; s >>= 1) { m10 += __shfl_xor(m10, s); m01 += __shfl_xor(m01, s); }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
