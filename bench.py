@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=500)
     ap.add_argument("--channels", type=int, default=3, choices=[1, 3])
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--smooth", type=int, default=0, help="3x3 box-blur passes over the synthetic frames (content with fewer, weaker corners; informational)")
     ap.add_argument("--contexts", type=int, default=1, help="independent contexts/streams the steps alternate over")
     args = ap.parse_args()
 
@@ -96,6 +97,10 @@ def main():
     # synthetic frames, a few unique pairs tiled to the batch; every copy is its own HBM region
     U = min(args.unique, B)
     gray, Htrue = synthetic.make_pair_batch(2, U, w, h)
+    for _ in range(max(args.smooth, 0)):                     # informational: lower-contrast, corner-poor content
+        g = np.pad(gray.astype(np.uint16), ((0, 0), (1, 1), (1, 1)), mode="edge")
+        acc = sum(g[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3))
+        gray = ((acc + 4) // 9).astype(np.uint8)
     host = gray if args.channels == 1 else synthetic.gray_to_bgr(gray)
     uniq = torch.from_numpy(np.ascontiguousarray(host)).to(dev)            # [2U, h, w(,3)]
     reps = -(-B // U)
@@ -255,7 +260,7 @@ def main():
                                    "RANSAC max 2000 conf 0.995 (BASELINE.json configs[1])"
                                    % (w, h, "BGR" if args.channels == 3 else "gray", B, args.nfeatures),
                        "pairs_per_step_per_gpu": B, "unique_pairs": U, "parallelism": "pairs sharded, dp%d" % world, "contexts_per_gpu": NCTX,
-                       "pairs_ok_fraction": ok_frac,
+                       "pairs_ok_fraction": ok_frac, "smooth_passes": args.smooth,
                        "arithmetic": "u8/i32 pixels+descriptors, f32 Harris+reprojection, f64 DLT+LM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
