@@ -388,6 +388,8 @@ int evh_fixed_plane_field(evh_ctx* c, const double* h_Hsup, int n, int w, int h,
 int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
                          int64_t row_stride, int64_t frame_stride, int nfeatures) {
   if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, "evh_orb_detect_batch: NULL argument");
+  const int share_group = c->fast_share_group;   // set by the pair / stream entries for THIS call only
+  c->fast_share_group = 0;
   if (nframes < 1 || nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "nframes exceeds max_frames");
   if (channels != 1 && channels != 3) return evh_fail(c, EVH_ERR_INVALID, "channels must be 1 or 3");
   if (row_stride < (int64_t)w * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
@@ -397,7 +399,7 @@ int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w
   if (rc) return rc;
   { EvhProfScope ps(c, EVH_ST_PYRAMID); rc = evh_launch_pyramid(c, nframes); }
   if (rc) return rc;
-  { EvhProfScope ps(c, EVH_ST_FAST); rc = evh_launch_fast(c, nframes); }
+  { EvhProfScope ps(c, EVH_ST_FAST); rc = evh_launch_fast(c, nframes, share_group); }
   if (rc) return rc;
   { EvhProfScope ps(c, EVH_ST_SELECT); rc = evh_launch_select(c, nframes); }
   if (rc) return rc;
@@ -571,6 +573,7 @@ int evh_pair_homography_batch(evh_ctx* c, const uint8_t* d_frames, int npairs, i
   if (mode != EVH_MODE_INDEPENDENT_PAIRS && mode != EVH_MODE_STREAM) return evh_fail(c, EVH_ERR_INVALID, "unknown mode");
   const int nframes = mode == EVH_MODE_INDEPENDENT_PAIRS ? 2 * npairs : npairs + 1;
   if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "batch needs more frame slots than max_frames");
+  c->fast_share_group = mode == EVH_MODE_INDEPENDENT_PAIRS ? 2 : nframes;   // the two frames of a pair / one stream
   int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
   if (rc) return rc;
   if (mode == EVH_MODE_INDEPENDENT_PAIRS) rc = match_pairs(c, npairs, 1, 2, 0, 2);
@@ -588,6 +591,7 @@ int evh_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nframes
   if (!c || !d_frames || !d_H || !d_status || nframes < 2) return evh_fail(c, EVH_ERR_INVALID, "evh_stream_homography_batch: bad argument");
   if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "chunk needs more frame slots than max_frames");
   const int npairs = nframes - 1;
+  c->fast_share_group = nframes;
   int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
   if (rc) return rc;
   if ((rc = match_pairs(c, npairs, 1, 1, 0, 1))) return rc;
@@ -652,6 +656,7 @@ int evh_multi_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int n
   const int64_t nframes64 = (int64_t)nstreams * frames_per_stream;
   if (nframes64 > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "batch needs more frame slots than max_frames");
   const int nframes = (int)nframes64;
+  c->fast_share_group = frames_per_stream;
   int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
   if (rc) return rc;
   // pair slot p = (frame p + 1, frame p): the slot that straddles two streams is computed and never read
@@ -672,6 +677,7 @@ int evh_stream_static_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, in
   if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "block needs more frame slots than max_frames");
   if (row_cap != c->kcap) return evh_fail(c, EVH_ERR_INVALID, "row_cap must equal evh_orb_capacity()");
   const int npairs = nframes - 1;
+  c->fast_share_group = nframes;
   int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
   if (rc) return rc;
   if ((rc = match_pairs(c, npairs, 1, 1, 0, 1))) return rc;      // orders itself behind a pending async solve

@@ -235,6 +235,10 @@ struct FastArgs {
   unsigned* shist;     // [F][8][256]
   int* redo;           // [F][8]
   int samp_start[EVH_NLEVELS], samp_mod[EVH_NLEVELS];   // sampling lattice of k_fast_sample
+  // consecutive frames of one video look alike: with share_group = F > 0 the frames of a call form groups of F
+  // consecutive frames and a frame at an odd position of its group takes the sampled score histogram of the frame
+  // before it instead of sampling itself (any threshold is exact; a wrong guess only costs the dense redo)
+  int share_group;
 };
 
 #define FT_W 128                 // output tile width (pixels)
@@ -590,6 +594,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
 __global__ __launch_bounds__(256) void k_fast_sample(FastArgs A) {
   __shared__ FastLds S;
   const int f = blockIdx.y;
+  if (A.share_group > 0 && ((f % A.share_group) & 1)) return;   // shares the histogram of frame f - 1
   int s = blockIdx.x, l = 0;
 #pragma unroll
   for (int i = 1; i < EVH_NLEVELS; i++)
@@ -622,7 +627,9 @@ __global__ void k_fast_thr(FastArgs A, int nframes) {
   int T = EVH_FAST_THR;
   if (mod > 0 && L.quota > 0) {
     const int need = max(24, (8 * L.quota + mod - 1) / mod);   // 4x the 2*quota corners the level must deliver
-    const unsigned* h = A.shist + (int64_t)i * 256;
+    const int f = i / EVH_NLEVELS;
+    const int src = (A.share_group > 0 && ((f % A.share_group) & 1)) ? i - EVH_NLEVELS : i;
+    const unsigned* h = A.shist + (int64_t)src * 256;
     int acc = 0;
     for (int s = 255; s > EVH_FAST_THR; s--) {
       acc += (int)h[s];
@@ -1132,7 +1139,7 @@ int evh_launch_pyramid(evh_ctx* c, int nframes) {
   return EVH_SUCCESS;
 }
 
-int evh_launch_fast(evh_ctx* c, int nframes) {
+int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
   EVH_HIP(c, hipMemsetAsync(c->d_cand_count, 0, sizeof(int) * EVH_NLEVELS * (size_t)nframes, c->stream));
   FastArgs A;
   for (int l = 0; l < EVH_NLEVELS; l++) A.lv[l] = c->g.lv[l];
@@ -1140,6 +1147,7 @@ int evh_launch_fast(evh_ctx* c, int nframes) {
   A.cand = c->d_cand; A.cand_frame_entries = c->g.cand_frame_entries;
   A.cand_count = c->d_cand_count;
   A.thr = c->d_fast_thr; A.shist = c->d_fast_hist; A.redo = c->d_fast_redo;
+  A.share_group = share_group > 1 ? share_group : 0;
   int nsamp = 0;
   for (int l = 0; l < EVH_NLEVELS; l++) {
     const int tiles = A.lv[l].tiles_x * A.lv[l].tiles_y;

@@ -68,6 +68,7 @@ struct evh_ctx {
   unsigned* d_fast_hist = nullptr;// [max_frames][8][256] sampled score histogram
   int* d_fast_redo = nullptr;     // [max_frames][8]
   bool fast_lift = true;
+  int fast_share_group = 0;       // frames per group of consecutive frames for this detect call (0: unrelated frames)
   // pair buffers (max_pairs = max_frames)
   int32_t* d_knn_idx = nullptr;   // [max_pairs][kcap][2]
   uint32_t* d_knn_d2 = nullptr;   // [max_pairs][kcap][2]
@@ -112,7 +113,7 @@ int evh_fail(evh_ctx* ctx, int code, const std::string& msg);
 int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int channels, int64_t row_stride,
                            int64_t frame_stride);
 int evh_launch_pyramid(evh_ctx* c, int nframes);
-int evh_launch_fast(evh_ctx* c, int nframes);
+int evh_launch_fast(evh_ctx* c, int nframes, int share_group);
 int evh_launch_select(evh_ctx* c, int nframes);
 int evh_launch_describe(evh_ctx* c, int nframes);
 int evh_launch_fixed_plane(evh_ctx* c, const double* d_H, int n, int w, int h, double* d_field, unsigned long long* d_max);

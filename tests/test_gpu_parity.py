@@ -646,3 +646,43 @@ def test_unaligned_and_padded_input_layout(ctx, cn):
         want = O.orb_pyramid(gray[f])
         for l in range(8):
             assert np.array_equal(ctx.download_level(f, l), want[l]), "level %d" % l
+
+
+def test_shared_threshold_between_consecutive_frames_is_exact():
+    """Pair / stream entries let the second frame of a pair (odd frames of a stream) reuse the sampled FAST score
+    histogram of the frame before it.  When the frames do NOT look alike -- a corner-rich frame followed by a
+    corner-poor one and the reverse -- the borrowed threshold is wrong and the dense redo must restore the exact
+    result; key points, descriptors and H still equal the oracle's."""
+    from evenvizion_amd._lib import Context
+    w, h = 1280, 720
+    rich, rich2, _ = S.make_pair(11, w, h)
+    poor = rich2.copy()
+    for _ in range(8):                                    # 8 passes of a 3x3 box blur: few, weak corners
+        g = np.pad(poor.astype(np.uint16), 1, mode="edge")
+        poor = ((sum(g[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) + 4) // 9).astype(np.uint8)
+    frames = np.stack([rich, poor, poor, rich, rich, rich2])     # pairs: (rich, poor), (poor, rich), (rich, rich2)
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=6)
+    try:
+        H = torch.zeros(3, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(frames), 3, 0, H, st)
+        c.synchronize()
+        for f in range(6):
+            o = O.orb_detect(frames[f]); g = c.orb_download(f)
+            assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"]), "frame %d" % f
+        Ho, so = O.pairs_gray_batch(frames)
+        assert np.array_equal(st.cpu().numpy(), so)
+        Hg = H.cpu().numpy().reshape(-1, 3, 3)
+        for p in range(3):
+            if so[p] == 0:
+                assert np.allclose(Hg[p], Ho[p], rtol=1e-9, atol=1e-12)
+        # the same frames as one stream (odd frames borrow from the frame before)
+        H5 = torch.zeros(5, 9, dtype=torch.float64, device="cuda")
+        st5 = torch.full((5,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(frames), 5, 1, H5, st5)
+        c.synchronize()
+        for f in range(6):
+            o = O.orb_detect(frames[f]); g = c.orb_download(f)
+            assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"]), "stream frame %d" % f
+    finally:
+        c.close()
