@@ -104,6 +104,20 @@ if f:
 b = os.path.join(src, "bench.json")
 if os.path.exists(b):
     line = open(b).read().strip().splitlines()[-1]
-    json.loads(line)
-    open(os.path.join(out, tag + "_bench_n1.json"), "w").write(line + "\n")
+    d = json.loads(line)
+    # the bench ran before this summary existed: put the traffic / VALU figures of THIS collection into its line
+    key = "fast@1280x720x1024_n500_c3"
+    try:
+        rf = d["roofline"]
+        tj = json.load(open(os.path.join(out, "traffic.json")))
+        if rf.get("kernel") == "fast" and key in tj:
+            rf["traffic"] = tj[key]
+        vj = json.load(open(os.path.join(out, "valu.json"))).get(key)
+        if vj and "valu_issue" in rf and rf.get("avg_launch_ms"):
+            rf["valu_issue"]["wave_insts_per_launch"] = vj["valu_wave_insts_per_launch"]
+            rf["valu_issue"]["per_clk_per_cu_at_2.4GHz"] = round(
+                vj["valu_wave_insts_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / (256 * 2.4e9), 3)
+    except Exception:
+        pass
+    open(os.path.join(out, tag + "_bench_n1.json"), "w").write(json.dumps(d) + "\n")
 print("profiles/ updated with tag", tag)
