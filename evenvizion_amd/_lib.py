@@ -37,6 +37,7 @@ SIGNATURES = {
     "evh_fixed_plane_field": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
     "evh_set_fast_lift": (_i, [_vp, _i]),
+    "evh_set_fast_share": (_i, [_vp, _i]),
     "evh_orb_count": (_i, [_vp, _i]),
     "evh_orb_capacity": (_i, [_vp]),
     "evh_orb_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -169,6 +170,9 @@ class Context:
 
     def set_fast_lift(self, on=True):
         self._check(self.lib.evh_set_fast_lift(self.h, int(bool(on))))
+
+    def set_fast_share(self, on=True):
+        self._check(self.lib.evh_set_fast_share(self.h, int(bool(on))))
 
     def fixed_plane_max(self, Hsup, w, h, field=None):
         """Hsup f64[n,3,3] -> f64[n]: max fixed-plane coordinate over the w x h grid of each matrix."""

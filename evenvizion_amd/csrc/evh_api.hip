@@ -246,7 +246,7 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_lvl_count, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_fast_thr, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_fast_hist, F * EVH_NLEVELS * 256));
-  A_(dalloc(c, &c->d_fast_redo, F * EVH_NLEVELS));
+  A_(dalloc(c, &c->d_fast_redo, F * EVH_NLEVELS + 1));
   A_(dalloc(c, &c->d_knn_idx, F * K * 2));
   A_(dalloc(c, &c->d_knn_d2, F * K * 2));
   A_(dalloc(c, &c->d_pts, F * K * 4));
@@ -288,6 +288,12 @@ void evh_destroy(evh_ctx* c) {
 int evh_set_fast_lift(evh_ctx* c, int on) {
   if (!c) return EVH_ERR_INVALID;
   c->fast_lift = on != 0;
+  return EVH_SUCCESS;
+}
+
+int evh_set_fast_share(evh_ctx* c, int on) {
+  if (!c) return EVH_ERR_INVALID;
+  c->fast_share = on != 0;
   return EVH_SUCCESS;
 }
 
@@ -388,7 +394,7 @@ int evh_fixed_plane_field(evh_ctx* c, const double* h_Hsup, int n, int w, int h,
 int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
                          int64_t row_stride, int64_t frame_stride, int nfeatures) {
   if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, "evh_orb_detect_batch: NULL argument");
-  const int share_group = c->fast_share_group;   // set by the pair / stream entries for THIS call only
+  const int share_group = c->fast_share ? c->fast_share_group : 0;   // set by the pair / stream entries for THIS call only
   c->fast_share_group = 0;
   if (nframes < 1 || nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "nframes exceeds max_frames");
   if (channels != 1 && channels != 3) return evh_fail(c, EVH_ERR_INVALID, "channels must be 1 or 3");

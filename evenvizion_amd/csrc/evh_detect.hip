@@ -233,7 +233,7 @@ struct FastArgs {
   // threshold lifting (k_fast_lift): per (frame, level) score threshold, sampled score histogram, redo flags
   int* thr;            // [F][8]
   unsigned* shist;     // [F][8][256]
-  int* redo;           // [F][8]
+  int* redo;           // [1 + F*8]: count, then the (frame * 8 + level) entries to redo densely
   int samp_start[EVH_NLEVELS], samp_mod[EVH_NLEVELS];   // sampling lattice of k_fast_sample
   // consecutive frames of one video look alike: with share_group = F > 0 the frames of a call form groups of F
   // consecutive frames and a frame at an odd position of its group takes the sampled score histogram of the frame
@@ -637,7 +637,7 @@ __global__ void k_fast_thr(FastArgs A, int nframes) {
     }
   }
   A.thr[i] = min(T, 126);   // the byte-parallel pre-test needs T + 1 <= 127; any T in (20, score range] is exact
-  A.redo[i] = 0;
+  if (i == 0) A.redo[0] = 0;                // work list of k_fast_redo: [0] = count, [1..] = frame * 8 + level
 }
 
 __global__ __launch_bounds__(256) void k_fast_main(FastArgs A) {
@@ -671,27 +671,32 @@ __global__ void k_fast_verify(FastArgs A, int nframes) {
   if (A.thr[i] > EVH_FAST_THR && A.cand_count[i] < 2 * A.lv[l].quota) {
     A.cand_count[i] = 0;
     A.thr[i] = EVH_FAST_THR;
-    A.redo[i] = 1;
+    A.redo[1 + atomicAdd(&A.redo[0], 1)] = i;
   }
 }
 
-// one workgroup per (level, frame); does nothing unless the level was flagged, then walks all its tiles
+// dense rescoring of the (frame, level) entries k_fast_verify listed: blockIdx.x = tile of the level, blockIdx.y
+// walks the list, so a flagged level is redone by all its tiles in parallel; with an empty list every workgroup leaves
+// at once
 __global__ __launch_bounds__(256) void k_fast_redo(FastArgs A) {
   __shared__ FastLds S;
-  const int l = blockIdx.x, f = blockIdx.y;
-  if (!A.redo[f * EVH_NLEVELS + l]) return;
-  const EvhLevel L = A.lv[l];
-  const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-  for (int t = 0; t < L.tiles_x * L.tiles_y; t++) {
-    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-    const int x0 = tx * FT_W, y0 = ty * FT_H;
+  const int count = A.redo[0];
+  for (int e = blockIdx.y; e < count; e += gridDim.y) {      // workgroup-uniform bounds
+    const int i = A.redo[1 + e];
+    const int f = i / EVH_NLEVELS, l = i - f * EVH_NLEVELS;
+    const EvhLevel L = A.lv[l];
+    const int t = blockIdx.x;
+    if (t < L.tiles_x * L.tiles_y) {
+      const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+      const int x0 = tx * FT_W, y0 = ty * FT_H;
+      fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
+      __syncthreads();
+      fast_dense_scores(S, L, x0, y0);
+      __syncthreads();
+      fast_nms_collect(S, L, x0, y0);
+      fast_emit(S, A, L, f, l);
+    }
     __syncthreads();
-    fast_stage(S, img, L, x0, y0);
-    __syncthreads();
-    fast_dense_scores(S, L, x0, y0);
-    __syncthreads();
-    fast_nms_collect(S, L, x0, y0);
-    fast_emit(S, A, L, f, l);
   }
 }
 
@@ -1167,7 +1172,7 @@ int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
   hipLaunchKernelGGL(k_fast_thr, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
   hipLaunchKernelGGL(k_fast_main, grid, dim3(256), 0, c->stream, A);
   hipLaunchKernelGGL(k_fast_verify, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
-  hipLaunchKernelGGL(k_fast_redo, dim3(EVH_NLEVELS, nframes), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL(k_fast_redo, dim3(A.lv[0].tiles_x * A.lv[0].tiles_y, std::min(nfl, 256)), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }

@@ -106,9 +106,12 @@ int evh_orb_detect_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int
  * either way (a level that comes up short is redone at threshold 20).  With lifting off the candidate lists
  * returned by evh_orb_download_candidates hold every FAST corner at threshold 20.                          */
 int evh_set_fast_lift(evh_ctx* ctx, int on);
-/* (The pair / stream entries below additionally let the second frame of a pair -- every other frame of a stream --
- * borrow the sampled score histogram of the frame before it: consecutive video frames look alike, and a threshold
- * that proves too high is redone at 20 like any other.  evh_orb_detect_batch itself samples every frame.)     */
+/* The pair / stream entries below additionally let the second frame of a pair -- every other frame of a stream --
+ * borrow the sampled score histogram of the frame before it (default on): consecutive video frames look alike, and
+ * a threshold that proves too high is redone at 20 like any other, so results never change.  Turn it off for
+ * batches of UNRELATED frame pairs, where the borrowed threshold is often wrong and the redo costs more than the
+ * sampling it saves.  evh_orb_detect_batch itself always samples every frame.                                */
+int evh_set_fast_share(evh_ctx* ctx, int on);
 /* number of keypoints of a frame slot, or <0 */
 int evh_orb_count(evh_ctx* ctx, int frame);
 /* capacity (rows) a caller must provide to evh_orb_download */

@@ -676,6 +676,14 @@ def test_shared_threshold_between_consecutive_frames_is_exact():
         for p in range(3):
             if so[p] == 0:
                 assert np.allclose(Hg[p], Ho[p], rtol=1e-9, atol=1e-12)
+        # sharing off: same result
+        c.set_fast_share(False)
+        Hn = torch.zeros(3, 9, dtype=torch.float64, device="cuda")
+        stn = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(frames), 3, 0, Hn, stn)
+        c.synchronize()
+        assert torch.equal(stn, st) and torch.equal(Hn, H)
+        c.set_fast_share(True)
         # the same frames as one stream (odd frames borrow from the frame before)
         H5 = torch.zeros(5, 9, dtype=torch.float64, device="cuda")
         st5 = torch.full((5,), -1, dtype=torch.int32, device="cuda")
