@@ -640,7 +640,7 @@ __global__ void k_fast_thr(FastArgs A, int nframes) {
   if (i == 0) A.redo[0] = 0;                // work list of k_fast_redo: [0] = count, [1..] = frame * 8 + level
 }
 
-__global__ __launch_bounds__(256) void k_fast_main(FastArgs A) {
+__global__ __launch_bounds__(256, 8) void k_fast_main(FastArgs A) {
   __shared__ FastLds S;
   const int f = blockIdx.y;
   int t = blockIdx.x;
