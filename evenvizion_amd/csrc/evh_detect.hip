@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
 //   k_fast_main:   all tiles at T (pre-test + queued exact scores; the dense path where T stayed 20);
 //   k_fast_verify: a lifted level that delivered fewer than 2*quota corners is reset ...
 //   k_fast_redo:   ... and redone at threshold 20.  The result equals the dense kernel's by construction.
-__global__ __launch_bounds__(256) void k_fast_sample(FastArgs A) {
+__global__ __launch_bounds__(256, 8) void k_fast_sample(FastArgs A) {
   __shared__ FastLds S;
   const int f = blockIdx.y;
   if (A.share_group > 0 && ((f % A.share_group) & 1)) return;   // shares the histogram of frame f - 1
@@ -994,11 +994,12 @@ __device__ __forceinline__ int gauss7(int a0, int a1, int a2, int a3, int a4, in
   return mad24s(18, a0 + a6, mad24s(34, a1 + a5, mad24s(49, a2 + a4, 55 * a3)));
 }
 
-__global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) {
+__global__ __launch_bounds__(64 * DW_PER_BLOCK, 6) void k_describe(DescribeArgs A) {
   __shared__ uint32_t raw32[DW_PER_BLOCK][DP_N * DP_STRIDE / 4];
   __shared__ uint16_t hbuf[DW_PER_BLOCK][DP_N * DH_STRIDE + 1];
-  __shared__ uint8_t blur[DW_PER_BLOCK][DB_N * DB_N + 3];
+  // the blurred patch (1524 B) reuses the raw patch's words: raw is dead once the horizontal pass has read it
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* blurp = reinterpret_cast<uint8_t*>(raw32[wv]);
   const int f = blockIdx.y;
   const int k = blockIdx.x * DW_PER_BLOCK + wv;
   if (k >= A.kp_count[f]) return;  // whole wave exits; only wave-level synchronisation is used below
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
     for (int r = 0; r < DB_N; r++) {
       const int rr = r + (DP_R - DB_R);
       const int sum = gauss7(h[rr - 3], h[rr - 2], h[rr - 1], h[rr], h[rr + 1], h[rr + 2], h[rr + 3]);
-      blur[wv][r * DB_N + lane] = (uint8_t)((sum + 32768) >> 16);
+      blurp[r * DB_N + lane] = (uint8_t)((sum + 32768) >> 16);
     }
   }
   WAVE_LDS_SYNC();
@@ -1094,8 +1095,8 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK) void k_describe(DescribeArgs A) 
     float px0 = (float)p[0], py0 = (float)p[1], px1 = (float)p[2], py1 = (float)p[3];
     float fx0 = px0 * a - py0 * b, fy0 = px0 * b + py0 * a;
     float fx1 = px1 * a - py1 * b, fy1 = px1 * b + py1 * a;
-    int t0 = blur[wv][((int)rintf(fy0) + DB_R) * DB_N + (int)rintf(fx0) + DB_R];
-    int t1 = blur[wv][((int)rintf(fy1) + DB_R) * DB_N + (int)rintf(fx1) + DB_R];
+    int t0 = blurp[((int)rintf(fy0) + DB_R) * DB_N + (int)rintf(fx0) + DB_R];
+    int t1 = blurp[((int)rintf(fy1) + DB_R) * DB_N + (int)rintf(fx1) + DB_R];
     bits[m] = __ballot(t0 < t1);
   }
   if (lane < 4) reinterpret_cast<unsigned long long*>(A.desc + o * 32)[lane] = bits[lane];
