@@ -994,12 +994,15 @@ __device__ __forceinline__ int gauss7(int a0, int a1, int a2, int a3, int a4, in
   return mad24s(18, a0 + a6, mad24s(34, a1 + a5, mad24s(49, a2 + a4, 55 * a3)));
 }
 
-__global__ __launch_bounds__(64 * DW_PER_BLOCK, 6) void k_describe(DescribeArgs A) {
-  __shared__ uint32_t raw32[DW_PER_BLOCK][DP_N * DP_STRIDE / 4];
-  __shared__ uint16_t hbuf[DW_PER_BLOCK][DP_N * DH_STRIDE + 1];
-  // the blurred patch (1524 B) reuses the raw patch's words: raw is dead once the horizontal pass has read it
+__global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs A) {
+  // ONE LDS region per wave (3.7 KB), used in turn as the raw patch (45 x 52 B), the horizontal-pass buffer
+  // (45 x 41 u16) and the blurred patch (39 x 39 B): every pass first loads all it needs into registers, a
+  // wave-level fence follows, only then does it store the next form over the same words.  14.8 KB per workgroup.
+  __shared__ uint32_t patch32[DW_PER_BLOCK][(DP_N * DH_STRIDE + 2) / 2 + 1];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint8_t* blurp = reinterpret_cast<uint8_t*>(raw32[wv]);
+  uint32_t* raw = patch32[wv];
+  uint16_t* hb = reinterpret_cast<uint16_t*>(patch32[wv]);
+  uint8_t* blurp = reinterpret_cast<uint8_t*>(patch32[wv]);
   const int f = blockIdx.y;
   const int k = blockIdx.x * DW_PER_BLOCK + wv;
   if (k >= A.kp_count[f]) return;  // whole wave exits; only wave-level synchronisation is used below
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 6) void k_describe(DescribeArgs 
     const int stride4 = L.stride >> 2;
     for (int i = lane; i < DP_N * (DP_STRIDE / 4); i += 64) {
       const int r = i / (DP_STRIDE / 4), c4 = i - r * (DP_STRIDE / 4);
-      raw32[wv][i] = src[mad24((uint32_t)(cy - DP_R + r), (uint32_t)stride4, (uint32_t)c4)];
+      raw[i] = src[mad24((uint32_t)(cy - DP_R + r), (uint32_t)stride4, (uint32_t)c4)];
     }
   }
 #define WAVE_LDS_SYNC()                                    \
@@ -1028,11 +1031,14 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 6) void k_describe(DescribeArgs 
   // ---- one lane per patch row: realign the row to the patch origin, then (a) orientation moments over the
   //      radius-15 disc and (b) the horizontal 7-tap pass with a sliding window
   int m10 = 0, m01 = 0;
+  uint32_t w[12];
   if (lane < DP_N) {
-    const uint32_t* rp = raw32[wv] + lane * (DP_STRIDE / 4);
-    uint32_t w[12];
+    const uint32_t* rp = raw + lane * (DP_STRIDE / 4);
 #pragma unroll
     for (int j = 0; j < 12; j++) w[j] = __builtin_amdgcn_alignbyte(rp[j + 1], rp[j], sh);
+  }
+  WAVE_LDS_SYNC();      // every row is in registers: the region may now take the horizontal-pass values
+  if (lane < DP_N) {
     const int v = lane - DP_R;
     // intensity-centroid moments over the disc as byte dot products: row bytes masked by the disc's extent in this
     // row, s0 = sum I, s1 = sum (u + 15) I - 15 s0 with u = c - 22 (weights 0..30 fit a byte); same integers as the
@@ -1056,7 +1062,7 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 6) void k_describe(DescribeArgs 
     // horizontal 7-tap pass as byte dot products: X(c) = the dword of bytes c..c+3 of the realigned row (every fourth
     // one is a register as it stands, the others one v_alignbyte), h(c) = dot4(X(c), {18,34,49,55}) +
     // dot4(X(c+4), {49,34,18,0}) -- the same integer as gauss7 on the seven bytes
-    uint16_t* hrow = hbuf[wv] + lane * DH_STRIDE;
+    uint16_t* hrow = hb + lane * DH_STRIDE;
     uint32_t X[DB_N + 4];
 #pragma unroll
     for (int c = 0; c < DB_N + 4; c++)
@@ -1070,11 +1076,14 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 6) void k_describe(DescribeArgs 
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   WAVE_LDS_SYNC();
   // ---- one lane per blurred column: vertical 7-tap pass, sliding down the 45 rows
+  int h[DP_N];
   if (lane < DB_N) {
-    const uint16_t* hc = hbuf[wv] + lane;
-    int h[DP_N];
+    const uint16_t* hc = hb + lane;
 #pragma unroll
     for (int r = 0; r < DP_N; r++) h[r] = hc[r * DH_STRIDE];
+  }
+  WAVE_LDS_SYNC();      // every column is in registers: the region may now take the blurred patch
+  if (lane < DB_N) {
 #pragma unroll
     for (int r = 0; r < DB_N; r++) {
       const int rr = r + (DP_R - DB_R);
