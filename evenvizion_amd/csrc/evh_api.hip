@@ -247,6 +247,8 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_fast_thr, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_fast_hist, F * EVH_NLEVELS * 256));
   A_(dalloc(c, &c->d_fast_redo, F * EVH_NLEVELS + 1));
+  A_(dalloc(c, &c->d_fast_hint, 16 + 8 * 256));
+  if (hipMemset(c->d_fast_hint, 0, sizeof(int) * (16 + 8 * 256)) != hipSuccess) return EVH_ERR_HIP;
   A_(dalloc(c, &c->d_knn_idx, F * K * 2));
   A_(dalloc(c, &c->d_knn_d2, F * K * 2));
   A_(dalloc(c, &c->d_pts, F * K * 4));
@@ -273,7 +275,7 @@ void evh_destroy(evh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
-                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

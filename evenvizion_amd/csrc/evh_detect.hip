@@ -239,6 +239,11 @@ struct FastArgs {
   // consecutive frames and a frame at an odd position of its group takes the sampled score histogram of the frame
   // before it instead of sampling itself (any threshold is exact; a wrong guess only costs the dense redo)
   int share_group;
+  // threshold hint carried from the previous detect call of this context (per level: the lower-quartile lifted
+  // threshold over the frames of that call, 0 = none): the sample pass then scores its tiles with the lifted machinery at 5/8 of the hint instead
+  // of densely -- the histogram is exact above that floor, which is where the new threshold will lie
+  const int* hint_in; int* hint_out;
+  unsigned* hint_hist;   // [8][256] votes of this call: the lifted threshold of every frame that sampled (bin 0: a failed level)
 };
 
 #define FT_W 128                 // output tile width (pixels)
@@ -607,15 +612,26 @@ __global__ __launch_bounds__(256, 8) void k_fast_sample(FastArgs A) {
   if (t >= L.tiles_x * L.tiles_y) return;
   const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
   const int x0 = tx * FT_W, y0 = ty * FT_H;
+  const int hint = A.hint_in[l];
+  const int Tp = (hint > 36 && hint < 256) ? max(EVH_FAST_THR + 1, (hint * 7) >> 3) : 0;   // 0: dense sample
   fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
   __syncthreads();
-  fast_dense_scores(S, L, x0, y0);
+  if (Tp) fast_lift_scores(S, L, x0, y0, Tp);          // exact scores >= Tp, zero elsewhere
+  else fast_dense_scores(S, L, x0, y0);
   __syncthreads();
   fast_nms_collect(S, L, x0, y0);
   __syncthreads();
   const int n = S.lcnt;
   unsigned* h = A.shist + (int64_t)(f * EVH_NLEVELS + l) * 256;
-  for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&h[S.lst[i] >> 24], 1u);
+  if (threadIdx.x == 0) h[0] = (unsigned)Tp;            // bin 0 (never a score) carries the floor of this histogram
+  // tile histogram in LDS first (the score plane is dead), then one global atomic per non-empty bin
+  uint32_t* lh = S.score;
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&lh[S.lst[i] >> 24], 1u);
+  __syncthreads();
+  const uint32_t cnt = lh[threadIdx.x];
+  if (cnt && threadIdx.x > EVH_FAST_THR) atomicAdd(&h[threadIdx.x], cnt);
 }
 
 __global__ void k_fast_thr(FastArgs A, int nframes) {
@@ -630,11 +646,14 @@ __global__ void k_fast_thr(FastArgs A, int nframes) {
     const int f = i / EVH_NLEVELS;
     const int src = (A.share_group > 0 && ((f % A.share_group) & 1)) ? i - EVH_NLEVELS : i;
     const unsigned* h = A.shist + (int64_t)src * 256;
+    const int floor_t = (int)h[0];                       // 0: dense histogram, else exact only from floor_t up
     int acc = 0;
-    for (int s = 255; s > EVH_FAST_THR; s--) {
+    T = floor_t ? floor_t : EVH_FAST_THR;                // not enough mass above the floor: take all of it (verify decides)
+    for (int s = 255; s > max(EVH_FAST_THR, floor_t - 1); s--) {
       acc += (int)h[s];
       if (acc >= need) { T = s; break; }
     }
+    if (src == i) atomicAdd(&A.hint_hist[l * 256 + (T > EVH_FAST_THR ? min(T, 255) : 0)], 1u);   // vote for the next call's hint
   }
   A.thr[i] = min(T, 126);   // the byte-parallel pre-test needs T + 1 <= 127; any T in (20, score range] is exact
   if (i == 0) A.redo[0] = 0;                // work list of k_fast_redo: [0] = count, [1..] = frame * 8 + level
@@ -672,7 +691,24 @@ __global__ void k_fast_verify(FastArgs A, int nframes) {
     A.cand_count[i] = 0;
     A.thr[i] = EVH_FAST_THR;
     A.redo[1 + atomicAdd(&A.redo[0], 1)] = i;
+    atomicAdd(&A.hint_hist[l * 256], 1u);               // a vote for 'no hint': the level came up short
   }
+}
+
+// next call's hint per level: the lower quartile of this call's votes (robust against a few odd frames; a frame whose
+// own threshold lies below 7/8 of it merely takes everything above that floor, and verify/redo stays the safety net)
+__global__ void k_fast_hint(FastArgs A) {
+  const int l = threadIdx.x;
+  if (l >= EVH_NLEVELS) return;
+  const unsigned* h = A.hint_hist + l * 256;
+  unsigned total = 0;
+  for (int s = 0; s < 256; s++) total += h[s];
+  int hint = 0;
+  if (total) {
+    unsigned acc = 0;
+    for (int s = 0; s < 256; s++) { acc += h[s]; if (4 * acc >= total) { hint = s; break; } }
+  }
+  A.hint_out[l] = hint;
 }
 
 // dense rescoring of the (frame, level) entries k_fast_verify listed: blockIdx.x = tile of the level, blockIdx.y
@@ -1163,6 +1199,10 @@ int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
   A.cand_count = c->d_cand_count;
   A.thr = c->d_fast_thr; A.shist = c->d_fast_hist; A.redo = c->d_fast_redo;
   A.share_group = share_group > 1 ? share_group : 0;
+  A.hint_in = c->d_fast_hint + 8 * c->fast_hint_idx;
+  A.hint_out = c->d_fast_hint + 8 * (c->fast_hint_idx ^ 1);
+  A.hint_hist = reinterpret_cast<unsigned*>(c->d_fast_hint + 16);
+  c->fast_hint_idx ^= 1;
   int nsamp = 0;
   for (int l = 0; l < EVH_NLEVELS; l++) {
     const int tiles = A.lv[l].tiles_x * A.lv[l].tiles_y;
@@ -1178,10 +1218,12 @@ int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
   }
   const int nfl = nframes * EVH_NLEVELS;
   EVH_HIP(c, hipMemsetAsync(c->d_fast_hist, 0, sizeof(unsigned) * 256 * (size_t)nfl, c->stream));
+  EVH_HIP(c, hipMemsetAsync(A.hint_hist, 0, sizeof(unsigned) * 8 * 256, c->stream));
   hipLaunchKernelGGL(k_fast_sample, dim3(nsamp, nframes), dim3(256), 0, c->stream, A);
   hipLaunchKernelGGL(k_fast_thr, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
   hipLaunchKernelGGL(k_fast_main, grid, dim3(256), 0, c->stream, A);
   hipLaunchKernelGGL(k_fast_verify, dim3((nfl + 255) / 256), dim3(256), 0, c->stream, A, nframes);
+  hipLaunchKernelGGL(k_fast_hint, dim3(1), dim3(64), 0, c->stream, A);
   hipLaunchKernelGGL(k_fast_redo, dim3(A.lv[0].tiles_x * A.lv[0].tiles_y, std::min(nfl, 256)), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;

@@ -66,6 +66,8 @@ struct evh_ctx {
   int* d_lvl_count = nullptr;     // [max_frames][8]
   int* d_fast_thr = nullptr;      // [max_frames][8] lifted FAST threshold
   unsigned* d_fast_hist = nullptr;// [max_frames][8][256] sampled score histogram
+  int* d_fast_hint = nullptr;     // [2][8] per-level threshold hint (ping-pong between detect calls) + [8][256] votes
+  int fast_hint_idx = 0;
   int* d_fast_redo = nullptr;     // [1 + max_frames*8] redo work list (count first)
   bool fast_lift = true;
   bool fast_share = true;         // evh_set_fast_share

@@ -694,3 +694,32 @@ def test_shared_threshold_between_consecutive_frames_is_exact():
             assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"]), "stream frame %d" % f
     finally:
         c.close()
+
+
+def test_threshold_hint_across_calls_is_exact():
+    """The sample pass of a detect call uses the lifted thresholds of the PREVIOUS call of the same context as a hint
+    (lifted scoring at 5/8 of it instead of dense scoring).  A stale hint -- rich content, then poor content, then rich
+    again, and a flat frame in between -- must never change a key point."""
+    from evenvizion_amd._lib import Context
+    w, h = 1280, 720
+    rich, rich2, _ = S.make_pair(21, w, h)
+    poor = rich2.copy()
+    for _ in range(8):
+        g = np.pad(poor.astype(np.uint16), 1, mode="edge")
+        poor = ((sum(g[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) + 4) // 9).astype(np.uint8)
+    flat = np.full((h, w), 77, np.uint8)
+    want = {id(x): O.orb_detect(x) for x in (rich, rich2, poor, flat)}
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=2)
+    try:
+        for seq in ([rich, rich2], [rich2, rich], [poor, poor], [rich, poor], [flat, rich], [rich, rich2], [poor, rich]):
+            c.orb_detect_batch(dev(np.stack(seq)))
+            c.synchronize()
+            for f, img in enumerate(seq):
+                o = want[id(img)]
+                if len(o["xy"]) == 0:
+                    assert c.lib.evh_orb_count(c.h, f) == 0
+                    continue
+                g = c.orb_download(f)
+                assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"])
+    finally:
+        c.close()
