@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=500)
     ap.add_argument("--channels", type=int, default=3, choices=[1, 3])
     ap.add_argument("--cpu-pairs", type=int, default=-1, help="pairs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-temporal", action="store_true", help="switch off the two exact shortcuts that lean on consecutive frames / calls looking alike (threshold sharing inside a pair, threshold hint across calls)")
     ap.add_argument("--smooth", type=int, default=0, help="3x3 box-blur passes over the synthetic frames (content with fewer, weaker corners; informational)")
     ap.add_argument("--contexts", type=int, default=1, help="independent contexts/streams the steps alternate over")
     args = ap.parse_args()
@@ -118,6 +119,8 @@ def main():
     # results are double-buffered so that a step never overwrites what the previous step's gather still reads.
     for c_ in ctxs:
         c_.set_async_solve(True)
+        if args.no_temporal:
+            c_.set_fast_share(False); c_.set_fast_hint(False)
     NBUF = 2 * NCTX
     Hs = [torch.zeros(B, 9, dtype=torch.float64, device=dev) for _ in range(NBUF)]
     sts = [torch.full((B,), -1, dtype=torch.int32, device=dev) for _ in range(NBUF)]
@@ -261,6 +264,7 @@ def main():
                                    % (w, h, "BGR" if args.channels == 3 else "gray", B, args.nfeatures),
                        "pairs_per_step_per_gpu": B, "unique_pairs": U, "parallelism": "pairs sharded, dp%d" % world, "contexts_per_gpu": NCTX,
                        "pairs_ok_fraction": ok_frac, "smooth_passes": args.smooth,
+                       "fast_threshold_sharing_in_pair": not args.no_temporal, "fast_threshold_hint_across_calls": not args.no_temporal,
                        "arithmetic": "u8/i32 pixels+descriptors, f32 Harris+reprojection, f64 DLT+LM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -38,6 +38,7 @@ SIGNATURES = {
     "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
     "evh_set_fast_lift": (_i, [_vp, _i]),
     "evh_set_fast_share": (_i, [_vp, _i]),
+    "evh_set_fast_hint": (_i, [_vp, _i]),
     "evh_orb_count": (_i, [_vp, _i]),
     "evh_orb_capacity": (_i, [_vp]),
     "evh_orb_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -170,6 +171,9 @@ class Context:
 
     def set_fast_lift(self, on=True):
         self._check(self.lib.evh_set_fast_lift(self.h, int(bool(on))))
+
+    def set_fast_hint(self, on=True):
+        self._check(self.lib.evh_set_fast_hint(self.h, int(bool(on))))
 
     def set_fast_share(self, on=True):
         self._check(self.lib.evh_set_fast_share(self.h, int(bool(on))))

@@ -247,8 +247,8 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_fast_thr, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_fast_hist, F * EVH_NLEVELS * 256));
   A_(dalloc(c, &c->d_fast_redo, F * EVH_NLEVELS + 1));
-  A_(dalloc(c, &c->d_fast_hint, 16 + 8 * 256));
-  if (hipMemset(c->d_fast_hint, 0, sizeof(int) * (16 + 8 * 256)) != hipSuccess) return EVH_ERR_HIP;
+  A_(dalloc(c, &c->d_fast_hint, 16 + 8 * 256 + 8));
+  if (hipMemset(c->d_fast_hint, 0, sizeof(int) * (16 + 8 * 256 + 8)) != hipSuccess) return EVH_ERR_HIP;
   A_(dalloc(c, &c->d_knn_idx, F * K * 2));
   A_(dalloc(c, &c->d_knn_d2, F * K * 2));
   A_(dalloc(c, &c->d_pts, F * K * 4));
@@ -290,6 +290,12 @@ void evh_destroy(evh_ctx* c) {
 int evh_set_fast_lift(evh_ctx* c, int on) {
   if (!c) return EVH_ERR_INVALID;
   c->fast_lift = on != 0;
+  return EVH_SUCCESS;
+}
+
+int evh_set_fast_hint(evh_ctx* c, int on) {
+  if (!c) return EVH_ERR_INVALID;
+  c->fast_hint = on != 0;
   return EVH_SUCCESS;
 }
 

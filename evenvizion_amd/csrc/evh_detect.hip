@@ -1199,7 +1199,7 @@ int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
   A.cand_count = c->d_cand_count;
   A.thr = c->d_fast_thr; A.shist = c->d_fast_hist; A.redo = c->d_fast_redo;
   A.share_group = share_group > 1 ? share_group : 0;
-  A.hint_in = c->d_fast_hint + 8 * c->fast_hint_idx;
+  A.hint_in = c->fast_hint ? c->d_fast_hint + 8 * c->fast_hint_idx : c->d_fast_hint + 16 + 8 * 256;   // off: all zero
   A.hint_out = c->d_fast_hint + 8 * (c->fast_hint_idx ^ 1);
   A.hint_hist = reinterpret_cast<unsigned*>(c->d_fast_hint + 16);
   c->fast_hint_idx ^= 1;

@@ -66,11 +66,12 @@ struct evh_ctx {
   int* d_lvl_count = nullptr;     // [max_frames][8]
   int* d_fast_thr = nullptr;      // [max_frames][8] lifted FAST threshold
   unsigned* d_fast_hist = nullptr;// [max_frames][8][256] sampled score histogram
-  int* d_fast_hint = nullptr;     // [2][8] per-level threshold hint (ping-pong between detect calls) + [8][256] votes
+  int* d_fast_hint = nullptr;     // [2][8] per-level threshold hint (ping-pong between detect calls) + [8][256] votes + [8] zeros
   int fast_hint_idx = 0;
   int* d_fast_redo = nullptr;     // [1 + max_frames*8] redo work list (count first)
   bool fast_lift = true;
   bool fast_share = true;         // evh_set_fast_share
+  bool fast_hint = true;          // evh_set_fast_hint
   int fast_share_group = 0;       // frames per group of consecutive frames for this detect call (0: unrelated frames)
   // pair buffers (max_pairs = max_frames)
   int32_t* d_knn_idx = nullptr;   // [max_pairs][kcap][2]

@@ -112,6 +112,10 @@ int evh_set_fast_lift(evh_ctx* ctx, int on);
  * batches of UNRELATED frame pairs, where the borrowed threshold is often wrong and the redo costs more than the
  * sampling it saves.  evh_orb_detect_batch itself always samples every frame.                                */
 int evh_set_fast_share(evh_ctx* ctx, int on);
+/* A context also carries, per pyramid level, the lower quartile of the lifted thresholds of its previous detect call as
+ * a hint for the next call's sampling pass (lifted instead of dense scoring of the sampled tiles; default on, results
+ * never change).  Off = every call samples densely, as a context's first call does.                            */
+int evh_set_fast_hint(evh_ctx* ctx, int on);
 /* number of keypoints of a frame slot, or <0 */
 int evh_orb_count(evh_ctx* ctx, int frame);
 /* capacity (rows) a caller must provide to evh_orb_download */
