@@ -723,3 +723,28 @@ def test_threshold_hint_across_calls_is_exact():
                 assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("nfeat", [37, 137, 1000, 3000])
+def test_other_key_point_budgets(nfeat):
+    """ORB's per-level quotas, the select capacities and the match/RANSAC row capacities all derive from nfeatures:
+    unusual budgets (tiny, odd, larger than the frame can deliver) must still reproduce the oracle."""
+    from evenvizion_amd._lib import Context
+    w, h = 640, 360
+    a, b, _ = S.make_pair(300 + nfeat, w, h)
+    fr = np.stack([a, b])
+    c = Context(device=0, max_w=w, max_h=h, max_features=nfeat, max_frames=2)
+    try:
+        H = torch.zeros(1, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(fr), 1, 0, H, st, nfeatures=nfeat)
+        c.synchronize()
+        for f in range(2):
+            o = O.orb_detect(fr[f], nfeatures=nfeat); g = c.orb_download(f)
+            assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"])
+        Ho, so = O.pairs_gray_batch(fr, nfeatures=nfeat)
+        assert st.cpu().numpy()[0] == so[0]
+        if so[0] == 0:
+            assert np.allclose(H.cpu().numpy().reshape(3, 3), Ho[0], rtol=1e-9, atol=1e-12)
+    finally:
+        c.close()
