@@ -253,12 +253,6 @@ struct FastArgs {
 #define FS_DW ((FT_W + 8) / 4)   // score row: x0-4 .. x0+131, 34 quads (dwords of 4 byte scores)
 #define FS_H (FT_H + 2)          // score rows: y0-1 .. y0+FT_H
 
-__device__ __forceinline__ int min3i(int a, int b, int c) {
-  int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
-}
-__device__ __forceinline__ int max3i(int a, int b, int c) {
-  int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
-}
 // byte B (relative to the quad's own dword M; -4..-1 = left neighbour dword, 4..7 = right neighbour dword)
 template <int B>
 __device__ __forceinline__ int rbyte(uint32_t L, uint32_t M, uint32_t R) {
