@@ -4,11 +4,21 @@
 // get_largest_group_points (utils.py:258-325), compute_homography (utils.py:328-363), matrix_superposition
 // (utils.py:118-145).
 //
-// One wavefront (64 lanes) per frame pair.  RANSAC hypotheses are evaluated four at a time -- one 4-point
-// hypothesis per 16-lane group: the sample sequence of the fixed-seed multiply-with-carry generator is advanced
-// by every lane identically, each group keeps its own quadruple, solves its normalised DLT (9x9 Jacobi
-// eigen-solver, f64, cooperative inside the group) and counts its inliers; a sequential replay in sample order
-// then applies "strictly more inliers wins" and the adaptive iteration bound exactly like a serial RANSAC.
+// Shape of the computation.  One workgroup of NW wavefronts per frame pair (or per stream in the sequential scan).
+// * RANSAC hypotheses are evaluated 4*NW at a time: every 16-lane row of every wave owns one 4-point hypothesis.  The
+//   sample sequence of the fixed-seed multiply-with-carry generator is advanced by every lane identically, each row
+//   keeps its own quadruple, solves its normalised DLT (9x9 Jacobi eigen-solver, f64) and counts its inliers; a
+//   sequential replay in sample order then applies "strictly more inliers wins" and the adaptive iteration bound
+//   exactly like a serial RANSAC (over-evaluated hypotheses are simply ignored).
+// * The eigen-solver (jacobi_rows) is the latency-critical piece: measured on this part a dependent f64 divide costs
+//   69 cycles, a square root 106, an LDS round trip 65-125 and one wave issues one instruction per ~5 cycles, so the
+//   solver is written to a budget of instructions per rotation: pivot search and the four index rescans are DPP
+//   reductions on the raw bits of |a_ij| (one v_max_u32_dpp per step), the rotated values never leave registers
+//   before they are rescanned, and the c/s/t scalars use the exact divide / square-root sequences without the range
+//   scaling they cannot need here (bit-identical results, a slow path covers out-of-range operands).
+// * Sums over points (centroids, L^T L, J^T J, J^T r, residual norms) keep the serial summation order of the operator
+//   being replaced: the points go through a 64-point LDS tile (all lanes compute their own point's terms), then one
+//   lane per output entry adds the tile's terms in point order.
 // All floating-point sums keep a fixed order (-ffp-contract=off); f64 throughout the solves, f32 for the
 // reprojection error, as the operator being replaced.
 #include "evh_internal.h"
@@ -18,54 +28,76 @@
 
 namespace {
 
-#define WSYNC() __syncthreads()
-#define NL 64          // lanes of the wavefront
-#define NG 4           // lane groups of 16: one 4-point hypothesis (or one refit / LM matrix) per group
-#define GL 16          // lanes per group
-#define NC NG          // LDS matrix columns (one per group)
-// upper-triangle index of (i, j), i <= j, of an N x N symmetric matrix (the eigen-solver only touches i <= j)
-__device__ __forceinline__ int tri_index(int N, int i, int j) { return i * N - (i * (i - 1)) / 2 + (j - i); }
-#define TRI(N, i, j) tri_index((N), (i), (j))
+#define NL 64          // lanes of a wavefront
+#define NG 4           // 16-lane rows per wavefront: one eigen-problem (one RANSAC hypothesis) per row
+#define GL 16          // lanes per row
+#define MS 9           // row stride (doubles) of the matrices held in LDS, for N = 8 and N = 9
+#define TS 11          // stride (doubles) of one point's terms in the LDS tile
+#define HB 2048        // displacement-histogram bins held in LDS (larger displacements take the quadratic path)
 
-struct RansacLds {
-  double A[45 * NC];   // per-group symmetric 9x9 (or 8x8), upper triangle, element-major: A[TRI(i,j)*NC + group]
-  double V[81 * NC];   // per-group eigenvectors (rows), element-major
-  double W[9 * NC];
-  int indR[9 * NC];
-  int indC[9 * NC];
-  double bestH[9];
-  double H[9];         // result of the last single-problem DLT / LM
-  double x[8], xd[8], v[8], d[8], D[8], tmpd[8], A8[64], Ap[64], Inv[64];
-  double sc[8];        // scalars: S, Sd, ...
-  int ib[8];           // ints: proceed flags, counts
-};
+// Ordering point between a cross-lane write and read of LDS / global scratch INSIDE one wavefront.  DS (and VMEM)
+// operations of one wave execute in order, so no wait is needed: this only pins the compiler's ordering.
+#define WSYNC()                                                \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
 
-// Cross-lane moves inside a 16-lane group as DPP register moves (a VALU op) instead of ds_bpermute round trips.
-// The four controls pair every lane with: its xor-1 / xor-2 neighbour (quad permutes), the mirrored lane of its
-// 8-lane half, the mirrored lane of its 16-lane row -- applied in that order a commutative/associative combine
-// leaves every lane of the group with the result over all 16 lanes.
+// ---- cross-lane reductions inside a 16-lane row (or one of its 8-lane halves) as DPP-fused integer min / max ------
 #define DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
 #define DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
 #define DPP_HALF_MIRROR 0x141
 #define DPP_ROW_MIRROR 0x140
 template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
-  return __hiloint2double(hi, lo);
+__device__ __forceinline__ unsigned dmax(unsigned v) {
+  return max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ int group_sum16(int v) {
-  v += dpp_i<DPP_XOR1>(v); v += dpp_i<DPP_XOR2>(v); v += dpp_i<DPP_HALF_MIRROR>(v); v += dpp_i<DPP_ROW_MIRROR>(v);
-  return v;
-}
-// (value, index) -> larger value, smaller index among equal values
 template <int CTRL>
-__device__ __forceinline__ void argmax_step(double& v, int& i) {
-  const double ov = dpp_d<CTRL>(v);
-  const int oi = dpp_i<CTRL>(i);
-  const bool take = ov > v || (ov == v && oi < i);
-  v = take ? ov : v; i = take ? oi : i;
+__device__ __forceinline__ unsigned dmin(unsigned v) {
+  return min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dadd(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned rmax8(unsigned v) { return dmax<DPP_HALF_MIRROR>(dmax<DPP_XOR2>(dmax<DPP_XOR1>(v))); }
+__device__ __forceinline__ unsigned rmin8(unsigned v) { return dmin<DPP_HALF_MIRROR>(dmin<DPP_XOR2>(dmin<DPP_XOR1>(v))); }
+__device__ __forceinline__ unsigned rmax16(unsigned v) { return dmax<DPP_ROW_MIRROR>(rmax8(v)); }
+__device__ __forceinline__ unsigned rmin16(unsigned v) { return dmin<DPP_ROW_MIRROR>(rmin8(v)); }
+__device__ __forceinline__ int rsum16(int v) {
+  return dadd<DPP_ROW_MIRROR>(dadd<DPP_HALF_MIRROR>(dadd<DPP_XOR2>(dadd<DPP_XOR1>(v))));
+}
+__device__ __forceinline__ unsigned hi32(double v) { return (unsigned)__double2hiint(v); }
+__device__ __forceinline__ unsigned lo32(double v) { return (unsigned)__double2loint(v); }
+__device__ __forceinline__ double mk64(unsigned hi, unsigned lo) { return __hiloint2double((int)hi, (int)lo); }
+
+// ---- exact f64 divide / square root without the range scaling (same instruction sequences the compiler emits for
+//      `/` and sqrt(), minus v_div_scale / v_div_fixup / v_ldexp): bit-identical whenever no intermediate leaves the
+//      normal range, which the callers guarantee (and check) ------------------------------------------------------
+struct Recip { double den, r; };
+__device__ __forceinline__ Recip recip_refined(double den) {
+  double r = __builtin_amdgcn_rcp(den);
+  double e = fma(-den, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-den, r, 1.0);
+  r = fma(r, e, r);
+  return Recip{den, r};
+}
+__device__ __forceinline__ double div_by(double num, const Recip& R) {
+  const double q = num * R.r;
+  const double rem = fma(-R.den, q, num);
+  return fma(rem, R.r, q);
+}
+__device__ __forceinline__ double sqrt_1_2(double x) {  // x in [1, 2]
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return g;
 }
 
 __device__ __forceinline__ double hyp(double a, double b) {
@@ -74,132 +106,174 @@ __device__ __forceinline__ double hyp(double a, double b) {
   if (b > 0) { a /= b; return b * sqrt(1 + a * a); }
   return 0;
 }
-
-// Symmetric eigen-solver (Jacobi with largest-pivot selection, eigenvalues sorted descending, eigenvectors = rows
-// of V), one matrix per 16-lane group, up to four groups of a wavefront at once.  Arithmetic and pivot order are
-// those of the serial algorithm (the first maximum in the scan order R0..R(N-2), C1..C(N-1)); inside a group the
-// pivot search is a 16-lane reduction, the 2N-2 element rotations run one per lane and the four index rescans on
-// four lanes; only the c/s/t scalar chain is serial.  Must be called by all 64 lanes; `active` is group-uniform.
-template <int N>
-__device__ void jacobi_group(RansacLds& S, int lane, bool active) {
-  const int g = lane >> 4, gl = lane & 15;
-#define A0(i, j) S.A[TRI(N, i, j) * NC + g]
-#define V0(i, j) S.V[((i) * N + (j)) * NC + g]
-#define W0(i) S.W[(i) * NC + g]
-#define IR0(i) S.indR[(i) * NC + g]
-#define IC0(i) S.indC[(i) * NC + g]
-  const double eps = DBL_EPSILON;
-  if (active) {
-    for (int e = gl; e < N * N; e += GL) { const int i = e / N, j = e - i * N; V0(i, j) = i == j ? 1.0 : 0.0; }
-    if (gl < N) W0(gl) = A0(gl, gl);
-    // initial indR (lanes 0..N-2 -> k) and indC (lanes 8.. -> k = 1..N-1): each lane scans its own row / column
-    if (gl < N - 1) {
-      const int k = gl;
-      int m = k + 1; double mv = fabs(A0(k, m));
-      for (int i = k + 2; i < N; i++) { double val = fabs(A0(k, i)); if (mv < val) mv = val, m = i; }
-      IR0(k) = m;
-    } else if (gl >= 8 && gl < 8 + N - 1) {
-      const int k = gl - 8 + 1;
-      int m = 0; double mv = fabs(A0(0, k));
-      for (int i = 1; i < k; i++) { double val = fabs(A0(i, k)); if (mv < val) mv = val, m = i; }
-      IC0(k) = m;
-    }
-  }
-  WSYNC();
-  bool done = !active;
-  const int maxIters = N * N * 30;
-  for (int iters = 0; iters < maxIters; iters++) {
-    if (__ballot(!done) == 0ull) break;
-    // ---- pivot: lane j < N-1 holds |A[j][indR[j]]|, lane 8+(i-1) holds |A[indC[i]][i]| (i = 1..N-1); lane order =
-    //      scan order, so "first maximum" = smallest lane among the equal maxima
-    double val = -1.0;
-    if (!done) {
-      if (gl < N - 1) val = fabs(A0(gl, IR0(gl)));
-      else if (gl >= 8 && gl < 8 + N - 1) { const int i = gl - 8 + 1; val = fabs(A0(IC0(i), i)); }
-    }
-    double mx = val;
-    int who = gl;              // first maximum in scan order = smallest lane among the equal maxima
-    argmax_step<DPP_XOR1>(mx, who); argmax_step<DPP_XOR2>(mx, who);
-    argmax_step<DPP_HALF_MIRROR>(mx, who); argmax_step<DPP_ROW_MIRROR>(mx, who);
-    int k = 0, l = 1;
-    double c = 1, sn = 0, t = 0;
-    if (!done) {
-      if (who < 8) { k = who; l = IR0(who); }
-      else { l = who - 8 + 1; k = IC0(l); }
-      const double p = A0(k, l);
-      if (fabs(p) <= eps) done = true;
-      else {
-        const double y = (W0(l) - W0(k)) * 0.5;
-        t = fabs(y) + hyp(p, y);
-        sn = hyp(p, t);
-        c = t / sn;
-        sn = p / sn; t = (p / t) * p;
-        if (y < 0) sn = -sn, t = -t;
-      }
-    }
-    WSYNC();   // every lane has read A[k][l], W[k], W[l] before they change
-    if (!done) {
-      if (gl == 0) { A0(k, l) = 0; W0(k) -= t; W0(l) += t; }
-      // rotations: lane r < N rotates the V pair of column r; lane N+j rotates the A pair of the j-th index != k, l
-      if (gl < N) {
-        const double a0 = V0(k, gl), b0 = V0(l, gl);
-        V0(k, gl) = a0 * c - b0 * sn; V0(l, gl) = a0 * sn + b0 * c;
-      } else if (gl - N < N - 2) {
-        int i = gl - N;
-        if (i >= k) i++;
-        if (i >= l) i++;
-        double* p0 = i < k ? &A0(i, k) : &A0(k, i);
-        double* p1 = i < l ? &A0(i, l) : &A0(l, i);
-        const double a0 = *p0, b0 = *p1;
-        *p0 = a0 * c - b0 * sn; *p1 = a0 * sn + b0 * c;
-      }
-    }
-    WSYNC();
-    // ---- rescan indR / indC of the two touched indices: four scans, one per quad of the group (quad 0: row k,
-    //      1: column k, 2: row l, 3: column l); a lane takes elements sl and sl+4 of its scan, the quad combines with
-    //      "larger value, smaller index on ties" = the first maximum of the serial strict-< scan
-    {
-      const int sc = gl >> 2, sl = gl & 3;
-      const int idx = sc < 2 ? k : l;
-      const bool rowscan = (sc & 1) == 0;
-      const bool want = !done && (rowscan ? idx < N - 1 : idx > 0);
-      double mv = -1.0; int m = 0x7FFFFFFF;
-      if (want) {
-        const int first = rowscan ? idx + 1 : 0, end = rowscan ? N : idx;     // elements [first, end)
-        const int i1 = first + sl, i2 = i1 + 4;
-        if (i1 < end) { mv = fabs(rowscan ? A0(idx, i1) : A0(i1, idx)); m = i1; }
-        if (i2 < end) { const double v2 = fabs(rowscan ? A0(idx, i2) : A0(i2, idx)); if (mv < v2) mv = v2, m = i2; }
-      }
-      argmax_step<DPP_XOR1>(mv, m); argmax_step<DPP_XOR2>(mv, m);
-      if (want && sl == 0) { if (rowscan) IR0(idx) = m; else IC0(idx) = m; }
-    }
-    WSYNC();
-  }
-  WSYNC();
-  // ---- sort eigenvalues (descending) with their eigenvector rows: selection sort
-  for (int k = 0; k < N - 1; k++) {
-    int m = k;
-    if (active) for (int i = k + 1; i < N; i++) if (W0(m) < W0(i)) m = i;
-    WSYNC();
-    if (active && k != m) {
-      if (gl == 0) { double tw = W0(m); W0(m) = W0(k); W0(k) = tw; }
-      if (gl >= 1 && gl <= N) { const int i = gl - 1; double tv = V0(m, i); V0(m, i) = V0(k, i); V0(k, i) = tv; }
-    }
-    WSYNC();
-  }
-#undef A0
-#undef V0
-#undef W0
-#undef IR0
-#undef IC0
+// the rotation scalars of one Jacobi step, plain form (reference order of operations)
+__device__ __noinline__ void rotation_scalars_slow(double p, double wk, double wl, double* c, double* s, double* t) {
+  const double y = (wl - wk) * 0.5;
+  double tt = fabs(y) + hyp(p, y);
+  double sn = hyp(p, tt);
+  *c = tt / sn;
+  sn = p / sn; tt = (p / tt) * p;
+  if (y < 0) sn = -sn, tt = -tt;
+  *s = sn; *t = tt;
+}
+// the same values with the short sequences: |p| > DBL_EPSILON is given, so hyp(p, y) >= |p| > 0, t >= |p| and the
+// second hyp() always takes its "b >= a" branch; (p / t) * p == (|p| / t) * |p| because IEEE division and
+// multiplication are sign-symmetric.  `ok` is false when an operand is too large for the unscaled sequences.
+__device__ __forceinline__ bool rotation_scalars(double p, double wk, double wl, double& c, double& s, double& t) {
+  const double y = (wl - wk) * 0.5;
+  const double ap = fabs(p), ay = fabs(y);
+  const bool pg = ap > ay;
+  const double hi = pg ? ap : ay;
+  double lo = pg ? ay : ap;
+  lo = lo < 1e-150 ? 0.0 : lo;                // such a quotient squared vanishes against 1 either way
+  const double q = div_by(lo, recip_refined(hi));
+  const double h = hi * sqrt_1_2(1.0 + q * q);
+  const double tt = ay + h;
+  const double q2 = div_by(ap, recip_refined(tt));
+  const double sn = tt * sqrt_1_2(1.0 + q2 * q2);
+  const Recip rs = recip_refined(sn);
+  c = div_by(tt, rs);
+  double ss = div_by(p, rs);
+  double t2 = q2 * ap;
+  if (y < 0) ss = -ss, t2 = -t2;
+  s = ss; t = t2;
+  return sn < 0x1p400;                        // also false for NaN
 }
 
-// de-normalise the smallest-eigenvalue eigenvector (row 8 of V, column `col`) into H (runKernel's tail)
-__device__ __forceinline__ void dlt_finish(RansacLds& S, int col, double cmx, double cmy, double smx, double smy,
-                                           double cMx, double cMy, double sMx, double sMy, double* H) {
-  double H0[9];
+struct RowMat {          // one eigen-problem: A full symmetric, V eigenvectors as rows, W eigenvalues, sort order
+  double A[MS * MS];
+  double V[MS * MS];
+  double W[MS];
+  int ord[12];           // ord[p] = index of the p-th largest eigenvalue (selection-sort order of the reference)
+};
+
+// Symmetric eigen-solver (Jacobi with largest-pivot selection; eigenvalues sorted descending through M.ord), one
+// matrix per 16-lane row, up to four rows of a wavefront at once.  Arithmetic and pivot order are those of the
+// serial algorithm (first maximum in the scan order R0..R(N-2), C1..C(N-1); indR / indC rescanned only for the two
+// rotated indices).  Lane roles inside a row (half = lanes 0-7 / 8-15, m = lane & 7):
+//   half 0: rotation index m,     owner of the column candidate C(m+1) = A[indC[m+1]][m+1], column rescans (i < K)
+//   half 1: rotation index m + 1, owner of the row candidate R(m) = A[m][indR[m]],         row rescans (j > K)
+// A is held as a full symmetric matrix (both mirrors written), so A[own][cidx] addresses either kind of candidate.
+// The diagonal of A is dead after W is taken from it (lanes k and l park their unused products there).
+// Must be called by all 64 lanes; `active` is row-uniform.
+template <int N>
+__device__ __forceinline__ void jacobi_rows(RowMat& M, int lane, bool active) {
+  const int gl = lane & 15, half = gl >> 3, m = gl & 7;
+  const int idx = half ? m + 1 : m;
+  const bool idx_ok = idx < N;
+  const int idx_c = idx_ok ? idx : 0;
+  const int own = half ? m : m + 1;
+  const bool own_ok = m <= N - 2;
+  const int own_c = own_ok ? own : 1;
+  const unsigned prio = half ? m : 8 + m;
+  const int vc = gl < N ? gl : 0;
+  double* A = M.A;
+  double* V = M.V;
+  double* Wd = M.W;
+  if (active) {
+    for (int e = gl; e < N * N; e += GL) { const int i = e / N, j = e - i * N; V[i * MS + j] = i == j ? 1.0 : 0.0; }
+    if (gl < N) Wd[gl] = A[gl * MS + gl];
+  }
+  // initial indR[own] / indC[own]: first maximum of the row right of / the column above the diagonal
+  int cidx = half ? own_c + 1 : 0;
+  double cval = 0;
+  if (active && own_ok) {
+    double mv = -1.0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) H0[i] = S.V[((8) * 9 + i) * NC + col];
+    for (int j = 0; j < N; j++) {
+      const bool in = half ? j > own : j < own;
+      const double v = fabs(A[own * MS + j]);
+      if (in && mv < v) mv = v, cidx = j;
+    }
+    cval = A[own * MS + cidx];
+  }
+  WSYNC();
+  bool act = active;
+  const int maxIters = N * N * 30;
+  for (int iters = 0; iters < maxIters; iters++) {
+    if (__ballot(act) == 0ull) break;
+    // ---- pivot: first maximum of |candidate| over the row's 2N-2 owners, in the order R0.., C1..
+    const bool cv = act && own_ok;
+    const unsigned ch = cv ? hi32(cval) & 0x7FFFFFFFu : 0u, cl = cv ? lo32(cval) : 0u;
+    const unsigned mh = rmax16(ch);
+    const unsigned ml = rmax16(ch == mh ? cl : 0u);
+    const bool win = cv && ch == mh && cl == ml;
+    const unsigned pack = (prio << 12) | ((hi32(cval) >> 31) << 8) | ((half ? own : cidx) << 4) | (half ? cidx : own);
+    const unsigned pk = rmin16(win ? pack : 0xFFFFFFFFu);
+    const double pabs = mk64(mh, ml);
+    if (pabs <= DBL_EPSILON) act = false;
+    const int k = act ? (pk >> 4) & 15 : 0, l = act ? pk & 15 : 1;
+    const double p = (pk >> 8) & 1 ? -pabs : pabs;
+    // ---- operands of this rotation (independent of c, s: issued before the scalar chain)
+    const double wk = Wd[k], wl = Wd[l];
+    const double a0 = A[idx_c * MS + k], b0 = A[idx_c * MS + l];
+    const double va = V[k * MS + vc], vb = V[l * MS + vc];
+    double c = 1, s = 0, t = 0;
+    const bool fine = rotation_scalars(p, wk, wl, c, s, t);
+    if (__ballot(act && !fine) != 0ull) {
+      double c2, s2, t2;
+      rotation_scalars_slow(p, wk, wl, &c2, &s2, &t2);
+      if (!fine) c = c2, s = s2, t = t2;
+    }
+    double u = a0 * c - b0 * s, v = a0 * s + b0 * c;
+    if (idx == l) u = 0;                        // A[k][l] = 0
+    if (idx == k) v = 0;
+    const double nva = va * c - vb * s, nvb = va * s + vb * c;
+    if (act) {
+      if (idx_ok) { A[idx * MS + k] = u; A[k * MS + idx] = u; A[idx * MS + l] = v; A[l * MS + idx] = v; }
+      if (gl < N) { V[k * MS + gl] = nva; V[l * MS + gl] = nvb; }
+      if (gl == 0) { Wd[k] = wk - t; Wd[l] = wl + t; }
+    }
+    WSYNC();
+    // ---- candidates: every owner re-reads its element (its index may be stale, its value never is) ...
+    const double fresh = A[own_c * MS + cidx];
+    // ---- ... and the owners of k and l rescan: half 0 the column above, half 1 the row right of the diagonal,
+    //      straight from the rotated values in registers (u = new A[idx][k], v = new A[idx][l])
+    const bool inu = idx_ok && (half ? idx > k : idx < k);
+    const bool inv = idx_ok && (half ? idx > l : idx < l);
+    const unsigned uh = inu ? hi32(u) & 0x7FFFFFFFu : 0u, ul = inu ? lo32(u) : 0u;
+    const unsigned vh = inv ? hi32(v) & 0x7FFFFFFFu : 0u, vl = inv ? lo32(v) : 0u;
+    const unsigned muh = rmax8(uh), mvh = rmax8(vh);
+    const unsigned mul_ = rmax8(uh == muh ? ul : 0u), mvl = rmax8(vh == mvh ? vl : 0u);
+    const unsigned pu = rmin8(inu && uh == muh && ul == mul_ ? (unsigned)(idx << 1) | (hi32(u) >> 31) : 0xFFFFFFFFu);
+    const unsigned pv = rmin8(inv && vh == mvh && vl == mvl ? (unsigned)(idx << 1) | (hi32(v) >> 31) : 0xFFFFFFFFu);
+    if (act) {
+      cval = fresh;
+      if (own == k) { cidx = (pu >> 1) & 15; cval = mk64(muh | (pu << 31), mul_); }
+      if (own == l) { cidx = (pv >> 1) & 15; cval = mk64(mvh | (pv << 31), mvl); }
+    }
+  }
+  WSYNC();
+  // ---- order of the eigenvalues (descending).  Distinct values: position = number of larger ones.  Equal values
+  //      (degenerate input): replay the reference's selection sort on the index list.
+  int gt = 0, eq = 0;
+  double w = 0;
+  if (active && gl < N) {
+    w = Wd[gl];
+#pragma unroll
+    for (int i = 0; i < N; i++) { const double wi = Wd[i]; gt += wi > w ? 1 : 0; eq += wi == w ? 1 : 0; }
+  }
+  const unsigned long long tie = __ballot(active && gl < N && eq != 1);   // != 1 also catches NaN
+  const bool row_tie = ((tie >> (lane & 48)) & 0xFFFFull) != 0ull;
+  if (active && gl < N && !row_tie) M.ord[gt] = gl;
+  if (active && row_tie && gl == 0) {
+    for (int i = 0; i < N; i++) M.ord[i] = i;
+    for (int a = 0; a < N - 1; a++) {
+      int mm = a;
+      for (int i = a + 1; i < N; i++) if (Wd[M.ord[mm]] < Wd[M.ord[i]]) mm = i;
+      const int tmp = M.ord[a]; M.ord[a] = M.ord[mm]; M.ord[mm] = tmp;
+    }
+  }
+  WSYNC();
+}
+
+// de-normalise the smallest-eigenvalue eigenvector into H (runKernel's tail)
+__device__ __forceinline__ void dlt_finish(const RowMat& M, double cmx, double cmy, double smx, double smy, double cMx,
+                                           double cMy, double sMx, double sMy, double* H) {
+  double H0[9];
+  const int r8 = M.ord[8];
+#pragma unroll
+  for (int i = 0; i < 9; i++) H0[i] = M.V[r8 * MS + i];
   const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
   const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
   double Ht[9], H1[9];
@@ -228,12 +302,23 @@ __device__ __forceinline__ double ltl_term(int j, int k, double x, double y, dou
 #undef LXS
 #undef LYS
 }
+// upper-triangle entry number e (0..44, row-major) of a 9x9 -> (j, k), j <= k
+__device__ __forceinline__ void tri9(int e, int& j, int& k) {
+  j = 0;
+  while (e >= 9 - j) { e -= 9 - j; j++; }
+  k = j + e;
+}
+__device__ __forceinline__ void tri8(int e, int& i, int& j) {
+  i = 0;
+  while (e >= 8 - i) { e -= 8 - i; i++; }
+  j = i + e;
+}
 
-// normalised DLT of each group's own 4 correspondences (M -> m): every lane of a group holds the same 4 rows.
-// `valid` is group-uniform; returns (group-uniform) whether a model was produced; H valid on every lane of the group.
-__device__ bool dlt4_group(RansacLds& S, int lane, bool valid, const float* Mx, const float* My, const float* mx,
-                           const float* my, double* H) {
-  const int g = lane >> 4, gl = lane & 15;
+// normalised DLT of each row's own 4 correspondences (M -> m): every lane of a row holds the same 4 points.
+// `valid` is row-uniform; returns (row-uniform) whether a model was produced; H valid on every lane of the row.
+__device__ __forceinline__ bool dlt4_rows(RowMat& M, int lane, bool valid, const float* Mx, const float* My,
+                                          const float* mx, const float* my, double* H) {
+  const int gl = lane & 15;
   double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) { cmx += mx[i]; cmy += my[i]; cMx += Mx[i]; cMy += My[i]; }
@@ -247,20 +332,20 @@ __device__ bool dlt4_group(RansacLds& S, int lane, bool valid, const float* Mx, 
                              fabs(sMy) < DBL_EPSILON);
   if (ok) {
     smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
-    for (int e = gl; e < 45; e += GL) {          // L^T L upper triangle, entry e <-> (j, k), rows summed in order
-      int j = 0, r = e;
-      while (r >= 9 - j) { r -= 9 - j; j++; }
-      const int k = j + r;
+    for (int e = gl; e < 45; e += GL) {          // L^T L upper triangle, entry e <-> (j, k), points summed in order
+      int j, k;
+      tri9(e, j, k);
       double acc = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++)
         acc += ltl_term(j, k, (mx[i] - cmx) * smx, (my[i] - cmy) * smy, (Mx[i] - cMx) * sMx, (My[i] - cMy) * sMy);
-      S.A[TRI(9, j, k) * NC + g] = acc;
+      M.A[j * MS + k] = acc;
+      M.A[k * MS + j] = acc;
     }
   }
   WSYNC();
-  jacobi_group<9>(S, lane, ok);
-  if (ok) dlt_finish(S, g, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
+  jacobi_rows<9>(M, lane, ok);
+  if (ok) dlt_finish(M, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
   return ok;
 }
 
@@ -270,6 +355,18 @@ struct Rng {  // multiply-with-carry generator, seeded with all ones for every f
   __device__ unsigned next() {
     state = (unsigned long long)(unsigned)state * 4164903690u + (unsigned)(state >> 32);
     return (unsigned)state;
+  }
+};
+// x % n for 32-bit x through the 64-bit reciprocal M = ceil(2^64 / n): floor(x * M / 2^64) == x / n for every 32-bit x
+struct FastMod {
+  unsigned n, mlo, mhi;
+  __device__ explicit FastMod(unsigned n_) : n(n_) {
+    const unsigned long long M = 0xFFFFFFFFFFFFFFFFull / n_ + 1ull;
+    mlo = (unsigned)M; mhi = (unsigned)(M >> 32);
+  }
+  __device__ __forceinline__ unsigned mod(unsigned x) const {
+    const unsigned long long t = (unsigned long long)x * mhi + __umulhi(x, mlo);
+    return x - (unsigned)(t >> 32) * n;
   }
 };
 
@@ -293,7 +390,7 @@ __device__ __forceinline__ double det3(const float* px, const float* py, int t0,
   return a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) + a02 * (a10 * a21 - a20 * a11);
 }
 
-__device__ bool check_subset4(const float* Mx, const float* My, const float* mx, const float* my) {
+__device__ __forceinline__ bool check_subset4(const float* Mx, const float* My, const float* mx, const float* my) {
   if (have_collinear4(Mx, My) || have_collinear4(mx, my)) return false;
   const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
   int negative = 0;
@@ -327,50 +424,90 @@ __device__ __forceinline__ int wave_sum(int v) {
   return v;
 }
 
-// ---- single-problem normalised DLT on `count` rows (ax,ay,bx,by): sums in row order, one lane per sum -------------
-__device__ bool dlt_rows(RansacLds& S, int lane, const float* rows, int count, double* Hout /* LDS */) {
+struct SolveLds {        // scratch of the single-problem stages (refit, LM): used by wave 0 only
+  double bestH[9];
+  double H[9];           // result of the last single-problem DLT / LM
+  double x[8], xd[8], v[8], d[8], D[8], tmpd[8], A8[64], Ap[64], Inv[64];
+  double sc[8];          // scalars: S, Sd, lambda, lc, nu, rmax ...
+  int ib[8];             // ints: proceed flags, counts
+  double T[NL * TS];     // the 64-point tile
+};
+
+// ---- single-problem normalised DLT on `count` rows (ax,ay,bx,by): sums in row order, one lane per sum; wave 0 ------
+__device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */) {
+  double* T = S.T;
   // centroids: lanes 0..3 own cm.x, cm.y, cM.x, cM.y  (m = b columns, M = a columns)
   double acc = 0;
-  if (lane < 4) {
-    const int col = lane == 0 ? 2 : lane == 1 ? 3 : lane == 2 ? 0 : 1;
-    for (int i = 0; i < count; i++) acc += rows[4 * i + col];
-    acc /= count;
+  for (int c0 = 0; c0 < count; c0 += NL) {
+    const int i = c0 + lane;
+    if (i < count) {
+      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+      T[lane * TS + 0] = r.z; T[lane * TS + 1] = r.w; T[lane * TS + 2] = r.x; T[lane * TS + 3] = r.y;
+    }
+    WSYNC();
+    const int cnt = min(NL, count - c0);
+    if (lane < 4) {
+#pragma unroll 8
+      for (int j = 0; j < cnt; j++) acc += T[j * TS + lane];
+    }
+    WSYNC();
   }
+  if (lane < 4) acc /= count;
   const double cmx = __shfl(acc, 0), cmy = __shfl(acc, 1), cMx = __shfl(acc, 2), cMy = __shfl(acc, 3);
   double dev = 0;
-  if (lane < 4) {
-    const int col = lane == 0 ? 2 : lane == 1 ? 3 : lane == 2 ? 0 : 1;
-    const double cc = lane == 0 ? cmx : lane == 1 ? cmy : lane == 2 ? cMx : cMy;
-    for (int i = 0; i < count; i++) dev += fabs(rows[4 * i + col] - cc);
+  const double mycen = lane == 0 ? cmx : lane == 1 ? cmy : lane == 2 ? cMx : cMy;
+  for (int c0 = 0; c0 < count; c0 += NL) {
+    const int i = c0 + lane;
+    if (i < count) {
+      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+      T[lane * TS + 0] = r.z; T[lane * TS + 1] = r.w; T[lane * TS + 2] = r.x; T[lane * TS + 3] = r.y;
+    }
+    WSYNC();
+    const int cnt = min(NL, count - c0);
+    if (lane < 4) {
+#pragma unroll 8
+      for (int j = 0; j < cnt; j++) dev += fabs(T[j * TS + lane] - mycen);
+    }
+    WSYNC();
   }
   double smx = __shfl(dev, 0), smy = __shfl(dev, 1), sMx = __shfl(dev, 2), sMy = __shfl(dev, 3);
   if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON)
     return false;
   smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
-  // LtL upper triangle: lane e <-> entry (j,k), sequential over rows
-  if (lane < 45) {
-    int j = 0, e = lane;
-    while (e >= 9 - j) { e -= 9 - j; j++; }
-    const int k = j + e;
-    double s = 0;
-    for (int i = 0; i < count; i++) {
-      double x = (rows[4 * i + 2] - cmx) * smx, y = (rows[4 * i + 3] - cmy) * smy;
-      double X = (rows[4 * i] - cMx) * sMx, Y = (rows[4 * i + 1] - cMy) * sMy;
-      double nxX = -x * X, nxY = -x * Y, nyX = -y * X, nyY = -y * Y;
-      // Lx = {X, Y, 1, 0, 0, 0, -xX, -xY, -x}; Ly = {0, 0, 0, X, Y, 1, -yX, -yY, -y}
-#define LXS(q) ((q) == 0 ? X : (q) == 1 ? Y : (q) == 2 ? 1.0 : (q) < 6 ? 0.0 : (q) == 6 ? nxX : (q) == 7 ? nxY : -x)
-#define LYS(q) ((q) < 3 ? 0.0 : (q) == 3 ? X : (q) == 4 ? Y : (q) == 5 ? 1.0 : (q) == 6 ? nyX : (q) == 7 ? nyY : -y)
-      s += LXS(j) * LXS(k) + LYS(j) * LYS(k);
-#undef LXS
-#undef LYS
+  // L^T L upper triangle: lane e <-> entry (j,k), sequential over the points.  A point's terms in the tile:
+  // 0:X 1:Y 2:1 3:0 4:-xX 5:-xY 6:-x 7:-yX 8:-yY 9:-y ; Lx = {0,1,2,3,3,3,4,5,6}, Ly = {3,3,3,0,1,2,7,8,9}
+  int ej = 0, ek = 0;
+  if (lane < 45) tri9(lane, ej, ek);
+  const int lxj = ej < 3 ? ej : ej < 6 ? 3 : ej - 2, lxk = ek < 3 ? ek : ek < 6 ? 3 : ek - 2;
+  const int lyj = ej < 3 ? 3 : ej < 6 ? ej - 3 : ej + 1, lyk = ek < 3 ? 3 : ek < 6 ? ek - 3 : ek + 1;
+  double s = 0;
+  for (int c0 = 0; c0 < count; c0 += NL) {
+    const int i = c0 + lane;
+    if (i < count) {
+      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+      const double x = (r.z - cmx) * smx, y = (r.w - cmy) * smy;
+      const double X = (r.x - cMx) * sMx, Y = (r.y - cMy) * sMy;
+      double* t = T + lane * TS;
+      t[0] = X; t[1] = Y; t[2] = 1.0; t[3] = 0.0; t[4] = -x * X; t[5] = -x * Y; t[6] = -x;
+      t[7] = -y * X; t[8] = -y * Y; t[9] = -y;
     }
-    S.A[TRI(9, j, k) * NC + 0] = s;  // column 0
+    WSYNC();
+    const int cnt = min(NL, count - c0);
+    if (lane < 45) {
+#pragma unroll 4
+      for (int j = 0; j < cnt; j++) {
+        const double* t = T + j * TS;
+        s += t[lxj] * t[lxk] + t[lyj] * t[lyk];
+      }
+    }
+    WSYNC();
   }
+  if (lane < 45) { M.A[ej * MS + ek] = s; M.A[ek * MS + ej] = s; }
   WSYNC();
-  jacobi_group<9>(S, lane, lane < GL);
+  jacobi_rows<9>(M, lane, lane < GL);
   if (lane == 0) {
     double H[9];
-    dlt_finish(S, 0, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
+    dlt_finish(M, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
     for (int i = 0; i < 9; i++) Hout[i] = H[i];
   }
   WSYNC();
@@ -378,32 +515,30 @@ __device__ bool dlt_rows(RansacLds& S, int lane, const float* rows, int count, d
 }
 
 // ---- symmetric solve / inverse through the eigen-decomposition (cv::solve / cv::invert, DECOMP_EIGEN) -------------
-// all 64 lanes; Ain / b / x live in LDS.  Back-substitution keeps the serial summation orders: lane i forms
+// all 64 lanes of wave 0; Ain / b / x live in LDS.  Back-substitution keeps the serial summation orders: lane i forms
 // s_i = (sum_j u_i[j] b[j]) / w_i, lane j accumulates x[j] += s_i u_i[j] over i ascending.
-__device__ void eig_solve8_wave(RansacLds& S, int lane, const double* Ain /*LDS 64*/, const double* b /*LDS 8 or null*/,
+__device__ __forceinline__ void eig_solve8_wave(RowMat& M, int lane, const double* Ain /*LDS 64*/, const double* b /*LDS 8 or null*/,
                                 double* x /*LDS 8 or 64*/) {
-  const int N = 8;
-  if (lane < 36) {
-    int i = 0, e = lane;
-    while (e >= 8 - i) { e -= 8 - i; i++; }
-    const int j = i + e;
-    S.A[TRI(8, i, j) * NC] = Ain[i * 8 + j];
+  {
+    const int i = lane >> 3, j = lane & 7;
+    M.A[i * MS + j] = Ain[min(i, j) * 8 + max(i, j)];
   }
   WSYNC();
-  jacobi_group<8>(S, lane, lane < GL);
+  jacobi_rows<8>(M, lane, lane < GL);
   double threshold = 0;
-  for (int i = 0; i < 8; i++) threshold += S.W[i * NC];
+  for (int i = 0; i < 8; i++) threshold += M.W[M.ord[i]];
   threshold *= DBL_EPSILON * 2;
   if (b) {
     // s_i on lane i (0 for skipped eigenvalues is NOT equivalent to skipping: keep a flag)
     double si = 0; bool use = false;
     if (lane < 8) {
-      double wi = S.W[lane * NC];
+      const int r = M.ord[lane];
+      double wi = M.W[r];
       if (!(fabs(wi) <= threshold)) {
         use = true;
         wi = 1 / wi;
         double acc = 0;
-        for (int j = 0; j < 8; j++) acc += S.V[(lane * N + j) * NC] * b[j];
+        for (int j = 0; j < 8; j++) acc += M.V[r * MS + j] * b[j];
         si = acc * wi;
       }
     }
@@ -411,7 +546,7 @@ __device__ void eig_solve8_wave(RansacLds& S, int lane, const double* Ain /*LDS 
     for (int i = 0; i < 8; i++) {
       const double s_i = __shfl(si, i);
       const int u_i = __shfl((int)use, i);
-      if (u_i && lane < 8) xj = xj + s_i * S.V[(i * N + lane) * NC];
+      if (u_i && lane < 8) xj = xj + s_i * M.V[M.ord[i] * MS + lane];
     }
     if (lane < 8) x[lane] = xj;
   } else {
@@ -419,103 +554,96 @@ __device__ void eig_solve8_wave(RansacLds& S, int lane, const double* Ain /*LDS 
     const int r = lane >> 3, j = lane & 7;
     double acc = 0;
     for (int i = 0; i < 8; i++) {
-      double wi = S.W[i * NC];
+      const int ri = M.ord[i];
+      double wi = M.W[ri];
       if (fabs(wi) <= threshold) continue;
       wi = 1 / wi;
-      const double sj = S.V[(i * N + j) * NC] * wi;
-      acc = acc + S.V[(i * N + r) * NC] * sj;
+      const double sj = M.V[ri * MS + j] * wi;
+      acc = acc + M.V[ri * MS + r] * sj;
     }
     x[r * 8 + j] = acc;
   }
   WSYNC();
 }
 
-// per-point residual pieces of the refinement callback: lm[4i..] = {ww, xi, yi}; returns nothing, all lanes help
-__device__ void lm_points(const float* rows, int count, const double* h /*LDS*/, double* lm, int lane) {
+// One pass of the refinement callback over the rows at parameters h[0..7] (LDS): S.sc[slotS] = sum of squared
+// residuals (groups of four, as cv::norm), S.sc[slotR] = max |residual|; with J also S.A8 = J^T J (mirrored) and
+// S.v = J^T r (four interleaved partial sums).  Wave 0, all 64 lanes.  A point's terms in the tile:
+// 0:Mx*ww 1:My*ww 2:ww 3:0 4:-Mx*ww*xi 5:-My*ww*xi 6:-Mx*ww*yi 7:-My*ww*yi 8:xi-mx 9:yi-my
+//   x-row of J = {0,1,2,3,3,3,4,5}, y-row = {3,3,3,0,1,2,6,7}
+__device__ __forceinline__ void lm_eval(SolveLds& S, int lane, const float* rows, int count, const double* h, bool withJ, int slotS,
+                        int slotR) {
+  double* T = S.T;
   const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7];
-  for (int i = lane; i < count; i += NL) {
-    double Mx = rows[4 * i], My = rows[4 * i + 1];
-    double ww = h6 * Mx + h7 * My + 1.;
-    ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
-    double xi = (h0 * Mx + h1 * My + h2) * ww;
-    double yi = (h3 * Mx + h4 * My + h5) * ww;
-    lm[4 * i] = ww; lm[4 * i + 1] = xi; lm[4 * i + 2] = yi;
-  }
-}
-
-// sum of squared residuals in the fixed "groups of four rows" order; lane 0
-__device__ double lm_norm_l2sqr(const float* rows, const double* lm, int count) {
-  double s = 0;
-  int i = 0;
-  for (; i + 1 < count; i += 2) {
-    double v0 = lm[4 * i + 1] - rows[4 * i + 2], v1 = lm[4 * i + 2] - rows[4 * i + 3];
-    double v2 = lm[4 * i + 5] - rows[4 * i + 6], v3 = lm[4 * i + 6] - rows[4 * i + 7];
-    s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
-  }
-  if (i < count) {
-    double v0 = lm[4 * i + 1] - rows[4 * i + 2], v1 = lm[4 * i + 2] - rows[4 * i + 3];
-    s += v0 * v0;
-    s += v1 * v1;
-  }
-  return s;
-}
-
-__device__ __forceinline__ double jsel(int q, double a0, double a1, double a2, double a6, double a7) {
-  // x-row of the Jacobian: {a0, a1, a2, 0, 0, 0, a6, a7}
-  return q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : q < 6 ? 0.0 : q == 6 ? a6 : a7;
-}
-__device__ __forceinline__ double jsely(int q, double a0, double a1, double a2, double a6, double a7) {
-  // y-row: {0, 0, 0, a0, a1, a2, a6, a7}
-  return q < 3 ? 0.0 : q == 3 ? a0 : q == 4 ? a1 : q == 5 ? a2 : q == 6 ? a6 : a7;
-}
-
-// A = J^T J (lanes 0..35, one upper-triangle entry each, rows in order) and v = J^T r (lanes 36..43, four
-// interleaved partial sums); results to LDS A8 (mirrored) and v.
-__device__ void lm_normal_eqs(RansacLds& S, const float* rows, const double* lm, int count, int lane) {
-  if (lane < 36) {
-    int i = 0, e = lane;
-    while (e >= 8 - i) { e -= 8 - i; i++; }
-    const int j = i + e;
-    double s = 0;
-    for (int p = 0; p < count; p++) {
-      double Mx = rows[4 * p], My = rows[4 * p + 1];
-      double ww = lm[4 * p], xi = lm[4 * p + 1], yi = lm[4 * p + 2];
-      double a0 = Mx * ww, a1 = My * ww;
-      double x6 = -Mx * ww * xi, x7 = -My * ww * xi, y6 = -Mx * ww * yi, y7 = -My * ww * yi;
-      s += jsel(i, a0, a1, ww, x6, x7) * jsel(j, a0, a1, ww, x6, x7);
-      s += jsely(i, a0, a1, ww, y6, y7) * jsely(j, a0, a1, ww, y6, y7);
-    }
-    S.A8[i * 8 + j] = s; S.A8[j * 8 + i] = s;
-  } else if (lane < 44) {
-    const int i = lane - 36;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int p = 0;
-    for (; p + 1 < count; p += 2) {
-      {
-        double Mx = rows[4 * p], My = rows[4 * p + 1];
-        double ww = lm[4 * p], xi = lm[4 * p + 1], yi = lm[4 * p + 2];
-        double a0 = Mx * ww, a1 = My * ww;
-        s0 += jsel(i, a0, a1, ww, -Mx * ww * xi, -My * ww * xi) * (xi - rows[4 * p + 2]);
-        s1 += jsely(i, a0, a1, ww, -Mx * ww * yi, -My * ww * yi) * (yi - rows[4 * p + 3]);
+  int ei = 0, ej = 0;
+  if (lane < 36) tri8(lane, ei, ej);
+  const int jxi = ei < 3 ? ei : ei < 6 ? 3 : ei - 2, jxj = ej < 3 ? ej : ej < 6 ? 3 : ej - 2;
+  const int jyi = ei < 3 ? 3 : ei < 6 ? ei - 3 : ei, jyj = ej < 3 ? 3 : ej < 6 ? ej - 3 : ej;
+  const int vi = lane - 36;                      // lanes 36..43: J^T r entry vi
+  const int vx = vi < 3 ? vi : vi < 6 ? 3 : vi - 2, vy = vi < 3 ? 3 : vi < 6 ? vi - 3 : vi;
+  double s = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, nrm = 0, rmax = 0;
+  for (int c0 = 0; c0 < count; c0 += NL) {
+    const int i = c0 + lane;
+    if (i < count) {
+      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+      const double Mx = r.x, My = r.y;
+      double ww = h6 * Mx + h7 * My + 1.;
+      ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+      const double xi = (h0 * Mx + h1 * My + h2) * ww;
+      const double yi = (h3 * Mx + h4 * My + h5) * ww;
+      const double rx = xi - r.z, ry = yi - r.w;
+      double* t = T + lane * TS;
+      t[8] = rx; t[9] = ry;
+      if (withJ) {
+        t[0] = Mx * ww; t[1] = My * ww; t[2] = ww; t[3] = 0.0;
+        t[4] = -Mx * ww * xi; t[5] = -My * ww * xi; t[6] = -Mx * ww * yi; t[7] = -My * ww * yi;
       }
-      {
-        const int q = p + 1;
-        double Mx = rows[4 * q], My = rows[4 * q + 1];
-        double ww = lm[4 * q], xi = lm[4 * q + 1], yi = lm[4 * q + 2];
-        double a0 = Mx * ww, a1 = My * ww;
-        s2 += jsel(i, a0, a1, ww, -Mx * ww * xi, -My * ww * xi) * (xi - rows[4 * q + 2]);
-        s3 += jsely(i, a0, a1, ww, -Mx * ww * yi, -My * ww * yi) * (yi - rows[4 * q + 3]);
+      rmax = fmax(rmax, fabs(rx));
+      rmax = fmax(rmax, fabs(ry));
+    }
+    WSYNC();
+    const int cnt = min(NL, count - c0);
+    if (withJ && lane < 36) {
+#pragma unroll 4
+      for (int j = 0; j < cnt; j++) {
+        const double* t = T + j * TS;
+        s += t[jxi] * t[jxj];
+        s += t[jyi] * t[jyj];
+      }
+    } else if (withJ && lane < 44) {
+      int j = 0;
+      for (; j + 1 < cnt; j += 2) {
+        const double* t = T + j * TS;
+        s0 += t[vx] * t[8];
+        s1 += t[vy] * t[9];
+        s2 += t[TS + vx] * t[TS + 8];
+        s3 += t[TS + vy] * t[TS + 9];
+      }
+      if (j < cnt) {                              // only at the very end (tiles hold an even number of points)
+        const double* t = T + j * TS;
+        s0 += t[vx] * t[8];
+        s0 += t[vy] * t[9];
+      }
+    } else if (lane == 44) {
+      int j = 0;
+      for (; j + 1 < cnt; j += 2) {
+        const double* t = T + j * TS;
+        const double v0 = t[8], v1 = t[9], v2 = t[TS + 8], v3 = t[TS + 9];
+        nrm += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+      }
+      if (j < cnt) {
+        const double* t = T + j * TS;
+        const double v0 = t[8], v1 = t[9];
+        nrm += v0 * v0;
+        nrm += v1 * v1;
       }
     }
-    if (p < count) {
-      double Mx = rows[4 * p], My = rows[4 * p + 1];
-      double ww = lm[4 * p], xi = lm[4 * p + 1], yi = lm[4 * p + 2];
-      double a0 = Mx * ww, a1 = My * ww;
-      s0 += jsel(i, a0, a1, ww, -Mx * ww * xi, -My * ww * xi) * (xi - rows[4 * p + 2]);
-      s0 += jsely(i, a0, a1, ww, -Mx * ww * yi, -My * ww * yi) * (yi - rows[4 * p + 3]);
-    }
-    S.v[i] = (s0 + s1 + s2 + s3) * 1.0;
+    WSYNC();
   }
+  for (int sft = 32; sft > 0; sft >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, sft));
+  if (withJ && lane < 36) { S.A8[ei * 8 + ej] = s; S.A8[ej * 8 + ei] = s; }
+  if (withJ && lane >= 36 && lane < 44) S.v[vi] = (s0 + s1 + s2 + s3) * 1.0;
+  if (lane == 44) { S.sc[slotS] = nrm; S.sc[slotR] = rmax; }
   WSYNC();
 }
 
@@ -526,17 +654,14 @@ __device__ __forceinline__ double dot8(const double* a, const double* b) {
   return r;
 }
 
-// Levenberg-Marquardt refinement of S.H[0..7] over `count` rows (<= 10 iterations). Returns iterations.
-__device__ int lm_refine(RansacLds& S, int lane, const float* rows, int count, double* lm) {
+// Levenberg-Marquardt refinement of S.H[0..7] over `count` rows (<= 10 iterations). Returns iterations.  Wave 0.
+// S.sc: 0 = S, 1 = rmax of the kept point, 2 = lambda, 3 = lc, 4 = nu, 5 = Sd, 6 = rmax of the trial point
+__device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const float* rows, int count) {
   const int maxIters = 10;
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   if (lane < 8) S.x[lane] = S.H[lane];
   WSYNC();
-  lm_points(rows, count, S.x, lm, lane);
-  __threadfence_block();
-  WSYNC();
-  if (lane == 0) S.sc[0] = lm_norm_l2sqr(rows, lm, count);  // S
-  lm_normal_eqs(S, rows, lm, count, lane);
+  lm_eval(S, lane, rows, count, S.x, true, 0, 1);
   if (lane < 8) S.D[lane] = S.A8[lane * 8 + lane];
   if (lane == 0) { S.sc[2] = 1; S.sc[3] = 0.75; }  // lambda, lc
   WSYNC();
@@ -547,17 +672,15 @@ __device__ int lm_refine(RansacLds& S, int lane, const float* rows, int count, d
       S.Ap[lane] = i == j ? S.A8[lane] + S.sc[2] * S.D[i] : S.A8[lane];
     }
     WSYNC();
-    eig_solve8_wave(S, lane, S.Ap, S.v, S.d);
+    eig_solve8_wave(M, lane, S.Ap, S.v, S.d);
     if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
     WSYNC();
-    lm_points(rows, count, S.xd, lm, lane);
-    __threadfence_block();
-    WSYNC();
+    lm_eval(S, lane, rows, count, S.xd, false, 5, 6);
     // trial residual -> Sd, gain ratio R; lane 0 decides, the (rare) inverse is done by the whole wave
     if (lane == 0) {
       const double Rlo = 0.25, Rhi = 0.75;
       double Sc = S.sc[0];
-      double Sd = lm_norm_l2sqr(rows, lm, count);
+      double Sd = S.sc[5];
       for (int i = 0; i < 8; i++) {  // tmpd = -A*d + 2*v  (four interleaved partial sums per row)
         const double* a = S.A8 + i * 8;
         const double* d = S.d;
@@ -580,12 +703,12 @@ __device__ int lm_refine(RansacLds& S, int lane, const float* rows, int count, d
         if (lambda == 0) need_inv = 1;
         else lambda *= nu;
       }
-      S.sc[2] = lambda; S.sc[3] = lc; S.sc[4] = nu; S.sc[5] = Sd;
+      S.sc[2] = lambda; S.sc[3] = lc; S.sc[4] = nu;
       S.ib[1] = need_inv;
     }
     WSYNC();
     if (S.ib[1]) {
-      eig_solve8_wave(S, lane, S.A8, nullptr, S.Inv);
+      eig_solve8_wave(M, lane, S.A8, nullptr, S.Inv);
       if (lane == 0) {
         double maxval = DBL_EPSILON;
         for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(S.Inv[i * 8 + i]));
@@ -595,32 +718,16 @@ __device__ int lm_refine(RansacLds& S, int lane, const float* rows, int count, d
       }
       WSYNC();
     }
-    if (lane == 0) {
-      const double Sc = S.sc[0], Sd = S.sc[5];
-      S.ib[0] = Sd < Sc ? 1 : 0;
-      if (Sd < Sc) {
-        S.sc[0] = Sd;
-        for (int i = 0; i < 8; i++) { double t = S.x[i]; S.x[i] = S.xd[i]; S.xd[i] = t; }
-      }
-    }
+    const bool accepted = S.sc[5] < S.sc[0];
     WSYNC();
-    const bool accepted = S.ib[0] != 0;
-    // residuals / Jacobian at the accepted point (lm currently holds the trial point's pieces = accepted x if taken)
     if (accepted) {
-      lm_normal_eqs(S, rows, lm, count, lane);
-    } else {
-      lm_points(rows, count, S.x, lm, lane);  // restore the pieces of the kept point for the norms below
-      __threadfence_block();
+      if (lane < 8) { const double t = S.x[lane]; S.x[lane] = S.xd[lane]; S.xd[lane] = t; }
       WSYNC();
+      lm_eval(S, lane, rows, count, S.x, true, 0, 1);   // residuals / Jacobian at the accepted point (S = Sd again)
     }
     iter++;
-    // norm(r, INF) of the accepted residual, norm(d, INF)
-    double rmax = 0;
-    for (int i = lane; i < count; i += NL) {
-      rmax = fmax(rmax, fabs(lm[4 * i + 1] - rows[4 * i + 2]));
-      rmax = fmax(rmax, fabs(lm[4 * i + 2] - rows[4 * i + 3]));
-    }
-    for (int s = 32; s > 0; s >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, s));
+    // norm(r, INF) of the kept residual, norm(d, INF)
+    const double rmax = S.sc[1];
     double dmax = 0;
     for (int i = 0; i < 8; i++) dmax = fmax(dmax, fabs(S.d[i]));
     const bool proceed = iter < maxIters && dmax >= epsx && rmax >= epsf;
@@ -632,42 +739,65 @@ __device__ int lm_refine(RansacLds& S, int lane, const float* rows, int count, d
   return iter;
 }
 
-// ---- cv2.findHomography(a, b, RANSAC, thr) on `n` rows; result in S.H (LDS), mask[n] in global. --------------------
-// scratch: crow = float rows [n][4] for the compacted inliers, lm = double [n][4].
-__device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, int n, double thr, int maxItersArg,
-                                     double conf, int force_max, uint8_t* mask, float* crow, double* lm, int* info) {
-  if (info && lane < 3) info[lane] = 0;
-  for (int i = lane; i < n; i += NL) mask[i] = 0;
+template <int NW>
+struct BlockLds {
+  RowMat m[NW][NG];
+  SolveLds s;
+  int hyp[2][NW * NG];    // per hypothesis of a chunk: valid << 31 | model << 30 | inlier count (double-buffered)
+  double Hsup[9], Hprev[9], Hcur[9];
+  int have_prev, gate;
+  unsigned hist[HB];      // static filter: population and first member of every displacement bin
+  unsigned first[HB];
+  unsigned long long red[NW];
+};
+
+// ---- cv2.findHomography(a, b, RANSAC, thr) on `n` rows; result in B.s.H (LDS), mask[n] in global.  All NW*64
+// threads of the workgroup call this; the return value is uniform.  scratch: crow = float rows [n][4] for the
+// compacted inliers.  Ends with a workgroup barrier.
+template <int NW>
+__device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const float* rows, int n, double thr, int maxItersArg, double conf,
+                                      int force_max, uint8_t* mask, float* crow, int* info) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15;
+  SolveLds& S = B.s;
+  if (info && tid < 3) info[tid] = 0;
+  for (int i = tid; i < n; i += NW * NL) mask[i] = 0;
   if (thr <= 0) thr = 3;
-  if (n < 4) return false;
+  if (n < 4) { __threadfence_block(); __syncthreads(); return false; }
   if (n == 4) {
-    bool ok = dlt_rows(S, lane, rows, 4, S.H);
-    if (!ok) return false;
-    if (lane < 4) mask[lane] = 1;
-    if (info && lane == 0) info[1] = 4;
-    return true;
+    if (wave == 0) {
+      const bool ok = dlt_rows(S, B.m[0][0], lane, rows, 4, S.H);
+      if (lane == 0) S.ib[2] = ok ? 1 : 0;
+      if (ok && lane < 4) mask[lane] = 1;
+      if (ok && info && lane == 0) info[1] = 4;
+    }
+    __threadfence_block();
+    __syncthreads();
+    return S.ib[2] != 0;
   }
   const float t = (float)(thr * thr);
+  const int HC = NW * NG;                 // hypotheses per chunk
+  const int myh = wave * NG + row;
+  RowMat& M = B.m[wave][row];
   Rng rng;
-  int niters = max(maxItersArg, 1), maxGood = 0, iter = 0, run = 0;
-  bool stop = false, any_found = false;
+  const FastMod fm((unsigned)n);
+  int niters = max(maxItersArg, 1), maxGood = 0, iter = 0, run = 0, chunk = 0;
+  bool stop = false;
   while (!stop && iter < niters) {
-    // every lane advances the generator identically through NG quadruples; the lanes of group h keep quadruple #h
-    const int grp = lane >> 4;
+    // every lane advances the generator identically through HC quadruples; the lanes of hypothesis h keep quadruple #h
     int my[4] = {0, 1, 2, 3};
-    for (int h = 0; h < NG; h++) {
+    for (int h = 0; h < HC; h++) {
       int q[4];
       for (int i = 0; i < 4;) {
         int idx_i;
         for (;;) {
-          idx_i = q[i] = (int)(rng.next() % (unsigned)n);
+          idx_i = q[i] = (int)fm.mod(rng.next());
           int j = 0;
           for (; j < i; j++) if (idx_i == q[j]) break;
           if (j == i) break;
         }
         i++;
       }
-      if (h == grp) { my[0] = q[0]; my[1] = q[1]; my[2] = q[2]; my[3] = q[3]; }
+      if (h == myh) { my[0] = q[0]; my[1] = q[1]; my[2] = q[2]; my[3] = q[3]; }
     }
     float Mx[4], My[4], mx[4], my_[4];
 #pragma unroll
@@ -677,72 +807,82 @@ __device__ bool find_homography_wave(RansacLds& S, int lane, const float* rows, 
     }
     const bool valid = check_subset4(Mx, My, mx, my_);
     double H[9];
-    const bool ok = dlt4_group(S, lane, valid, Mx, My, mx, my_, H);
+    const bool ok = dlt4_rows(M, lane, valid, Mx, My, mx, my_, H);
     int good = 0;
-    if (ok) {   // the 16 lanes of the group split the points; integer count, order-free
+    if (ok) {   // the 16 lanes of the row split the points; integer count, order-free
       float Hf[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
-      for (int i = lane & 15; i < n; i += GL) {
+#pragma unroll 4
+      for (int i = gl; i < n; i += GL) {
         const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
         good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
       }
     }
-    good = group_sum16(good);
-    const unsigned long long vmask = __ballot(valid), okmask = __ballot(ok);
-    // sequential replay in sample order
-    for (int h = 0; h < NG; h++) {
-      if (!((vmask >> (GL * h)) & 1ull)) {  // rejected sample: counts towards the 10000-attempt bound of one draw
+    good = rsum16(good);
+    int* hyp = B.hyp[chunk & 1];
+    if (gl == 0) hyp[myh] = (valid ? 0x80000000u : 0u) | (ok ? 0x40000000u : 0u) | (unsigned)good;
+    __syncthreads();
+    // sequential replay in sample order (every thread, identically)
+    int best_h = -1;
+    for (int h = 0; h < HC; h++) {
+      const unsigned e = (unsigned)hyp[h];
+      if (!(e >> 31)) {  // rejected sample: counts towards the 10000-attempt bound of one draw
         if (++run >= 10000) { stop = true; break; }
         continue;
       }
       run = 0;
       if (iter >= niters) { stop = true; break; }
       iter++;
-      any_found = true;
-      if (!((okmask >> (GL * h)) & 1ull)) continue;
-      const int g = __shfl(good, GL * h);
+      if (!((e >> 30) & 1u)) continue;
+      const int g = (int)(e & 0x3FFFFFFFu);
       if (g > max(maxGood, 3)) {
         maxGood = g;
-        if (lane == GL * h) {
-#pragma unroll
-          for (int i = 0; i < 9; i++) S.bestH[i] = H[i];
-        }
+        best_h = h;
         if (!force_max) niters = update_num_iters(conf, (double)(n - g) / n, 4, niters);
       }
     }
-  }
-  WSYNC();
-  (void)any_found;
-  if (info && lane == 0) { info[0] = iter; info[1] = maxGood; }
-  if (maxGood <= 0) return false;
-  // inlier mask of the winning hypothesis + ordered compaction of its inliers
-  float Hf[8];
+    if (best_h == myh && gl == 0) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) Hf[i] = (float)S.bestH[i];
-  int ni = 0;
-  for (int c0 = 0; c0 < n; c0 += NL) {
-    const int i = c0 + lane;
-    bool in = false;
-    float4 r = make_float4(0, 0, 0, 0);
-    if (i < n) {
-      r = *reinterpret_cast<const float4*>(rows + 4 * i);
-      in = is_inlier(Hf, r.x, r.y, r.z, r.w, t);
-      mask[i] = in ? 1 : 0;
+      for (int i = 0; i < 9; i++) S.bestH[i] = H[i];
     }
-    const unsigned long long m = __ballot(in);
-    if (in) *reinterpret_cast<float4*>(crow + 4 * (ni + __popcll(m & ((1ull << lane) - 1ull)))) = r;
-    ni += __popcll(m);
+    chunk++;
   }
   __threadfence_block();
-  WSYNC();
-  if (lane < 9) S.H[lane] = S.bestH[lane];
-  WSYNC();
-  if (ni > 0) {
-    dlt_rows(S, lane, crow, ni, S.H);  // keeps the RANSAC model when the refit is degenerate
-    int it = lm_refine(S, lane, crow, ni, lm);
-    if (info && lane == 0) info[2] = it;
+  __syncthreads();
+  if (info && tid == 0) { info[0] = iter; info[1] = maxGood; }
+  if (maxGood <= 0) return false;
+  if (wave == 0) {
+    // inlier mask of the winning hypothesis + ordered compaction of its inliers
+    float Hf[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) Hf[i] = (float)S.bestH[i];
+    int ni = 0;
+    for (int c0 = 0; c0 < n; c0 += NL) {
+      const int i = c0 + lane;
+      bool in = false;
+      float4 r = make_float4(0, 0, 0, 0);
+      if (i < n) {
+        r = *reinterpret_cast<const float4*>(rows + 4 * i);
+        in = is_inlier(Hf, r.x, r.y, r.z, r.w, t);
+        mask[i] = in ? 1 : 0;
+      }
+      const unsigned long long mm = __ballot(in);
+      if (in) *reinterpret_cast<float4*>(crow + 4 * (ni + __popcll(mm & ((1ull << lane) - 1ull)))) = r;
+      ni += __popcll(mm);
+    }
+    __threadfence_block();
+    WSYNC();
+    if (lane < 9) S.H[lane] = S.bestH[lane];
+    WSYNC();
+    if (ni > 0) {
+      dlt_rows(S, B.m[0][0], lane, crow, ni, S.H);  // keeps the RANSAC model when the refit is degenerate
+      const int it = lm_refine(S, B.m[0][0], lane, crow, ni);
+      if (info && lane == 0) info[2] = it;
+    }
   }
+  __threadfence_block();
+  __syncthreads();
   return true;
 }
 
@@ -753,59 +893,88 @@ __device__ __forceinline__ void hdot(const double* H, double x, double y, double
   *tw = fma(H[6], x, H[7] * y) + H[8];
 }
 
-// find_point_displacement + get_largest_group_points; rbin = int scratch [n]; returns kept count
-__device__ int static_filter_wave(int lane, const double* H /*LDS or regs-uniform*/, const float* rows, int n, int* rbin,
-                                  float* out) {
-  for (int i = lane; i < n; i += NL) {
+// find_point_displacement + get_largest_group_points; rbin = int scratch [n] (global); returns kept count (uniform).
+// All threads of the workgroup; ends with a workgroup barrier.
+template <int NW>
+__device__ __forceinline__ int static_filter_block(BlockLds<NW>& B, const double* H /*LDS*/, const float* rows, int n, int* rbin,
+                                   float* out) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NT = NW * NL;
+  for (int i = tid; i < HB; i += NT) { B.hist[i] = 0u; B.first[i] = 0xFFFFFFFFu; }
+  __syncthreads();
+  int big = 0;
+  for (int i = tid; i < n; i += NT) {
     double tx, ty, tw;
     hdot(H, (double)rows[4 * i], (double)rows[4 * i + 1], &tx, &ty, &tw);
     double dx = tx / tw - (double)rows[4 * i + 2], dy = ty / tw - (double)rows[4 * i + 3];
     double dist = sqrt(dx * dx + dy * dy);
-    rbin[i] = (int)__builtin_rint(dist);  // Python round(): half to even
+    const int r = (int)__builtin_rint(dist);  // Python round(): half to even
+    rbin[i] = r;
+    if ((unsigned)r < (unsigned)HB) { atomicAdd(&B.hist[r], 1u); atomicMin(&B.first[r], (unsigned)i); }
+    else big = 1;
   }
   __threadfence_block();
-  WSYNC();
+  big = __syncthreads_or(big);
+  if (n == 0) return 0;
   // most populated bin; ties -> the bin whose first member comes first
   unsigned long long bestkey = 0;
-  for (int i = lane; i < n; i += NL) {
-    const int r = rbin[i];
-    bool first = true;
-    int cnt = 0;
-    for (int j = 0; j < n; j++) {
-      const int rj = rbin[j];
-      if (rj == r) { cnt++; if (j < i) first = false; }
+  if (!big) {
+    for (int b = tid; b < HB; b += NT) {
+      const unsigned cnt = B.hist[b];
+      if (cnt) {
+        const unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0x7FFFFFFF - (int)B.first[b]);
+        bestkey = key > bestkey ? key : bestkey;
+      }
     }
-    if (first) {
-      unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0x7FFFFFFF - i);
-      bestkey = key > bestkey ? key : bestkey;
+  } else {
+    for (int i = tid; i < n; i += NT) {
+      const int r = rbin[i];
+      bool first = true;
+      int cnt = 0;
+      for (int j = 0; j < n; j++) {
+        const int rj = rbin[j];
+        if (rj == r) { cnt++; if (j < i) first = false; }
+      }
+      if (first) {
+        unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0x7FFFFFFF - i);
+        bestkey = key > bestkey ? key : bestkey;
+      }
     }
   }
   for (int s = 32; s > 0; s >>= 1) {
     unsigned long long o = __shfl_xor(bestkey, s);
     bestkey = o > bestkey ? o : bestkey;
   }
-  if (n == 0) return 0;
+  if (lane == 0) B.red[wave] = bestkey;
+  __syncthreads();
+  for (int w = 0; w < NW; w++) { const unsigned long long o = B.red[w]; bestkey = o > bestkey ? o : bestkey; }
   const int ibest = 0x7FFFFFFF - (int)(bestkey & 0xFFFFFFFFull);
   const int rbest = rbin[ibest];
-  int m = 0;
-  for (int c0 = 0; c0 < n; c0 += NL) {
-    const int i = c0 + lane;
-    const bool f = i < n && rbin[i] == rbest;
-    const unsigned long long b = __ballot(f);
-    if (f) *reinterpret_cast<float4*>(out + 4 * (m + __popcll(b & ((1ull << lane) - 1ull)))) =
-        *reinterpret_cast<const float4*>(rows + 4 * i);
-    m += __popcll(b);
+  int mcount = 0;
+  if (wave == 0) {
+    for (int c0 = 0; c0 < n; c0 += NL) {
+      const int i = c0 + lane;
+      const bool f = i < n && rbin[i] == rbest;
+      const unsigned long long b = __ballot(f);
+      if (f) *reinterpret_cast<float4*>(out + 4 * (mcount + __popcll(b & ((1ull << lane) - 1ull)))) =
+          *reinterpret_cast<const float4*>(rows + 4 * i);
+      mcount += __popcll(b);
+    }
+    if (lane == 0) B.s.ib[3] = mcount;
   }
-  return m;
+  __threadfence_block();
+  __syncthreads();
+  return B.s.ib[3];
 }
 
 // compute_homography (utils.py:351-362): optional pre-transform by Hsup (f64 -> f32), RANSAC #2, 0.7 gate.
-__device__ int compute_homography_wave(RansacLds& S, int lane, const float* rows, int n, const double* Hsup /*LDS|null*/,
-                                       const EvhRansacArgs& A, uint8_t* mask, float* trow, float* crow, double* lm,
-                                       int* info) {
+// All threads; uniform result; ends with a workgroup barrier.
+template <int NW>
+__device__ __forceinline__ int compute_homography_block(BlockLds<NW>& B, const float* rows, int n, const double* Hsup /*LDS|null*/,
+                                        const EvhRansacArgs& A, uint8_t* mask, float* trow, float* crow, int* info) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* use = rows;
   if (Hsup) {
-    for (int i = lane; i < n; i += NL) {
+    for (int i = tid; i < n; i += NW * NL) {
       double tx, ty, tw;
       hdot(Hsup, (double)rows[4 * i], (double)rows[4 * i + 1], &tx, &ty, &tw);
       float ax = (float)(tx / tw), ay = (float)(ty / tw);
@@ -814,105 +983,108 @@ __device__ int compute_homography_wave(RansacLds& S, int lane, const float* rows
       *reinterpret_cast<float4*>(trow + 4 * i) = make_float4(ax, ay, bx, by);
     }
     __threadfence_block();
-    WSYNC();
+    __syncthreads();
     use = trow;
   }
-  const bool found = find_homography_wave(S, lane, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, lm, info);
-  __threadfence_block();
-  WSYNC();
-  int s = 0;
-  for (int i = lane; i < n; i += NL) s += mask[i];
-  s = wave_sum(s);
-  if ((double)s < 0.7 * (double)n) return EVH_PAIR_LOW_INLIER_RATIO;
+  const bool found = find_homography_block<NW>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info);
+  if (wave == 0) {
+    int s = 0;
+    for (int i = lane; i < n; i += NL) s += mask[i];
+    s = wave_sum(s);
+    if (lane == 0) B.gate = (double)s < 0.7 * (double)n ? 1 : 0;
+  }
+  __syncthreads();
+  if (B.gate) return EVH_PAIR_LOW_INLIER_RATIO;
   if (!found) return EVH_PAIR_NO_FINAL_H;
   return EVH_PAIR_OK;
 }
 
-__shared__ RansacLds g_lds;
+template <int NW>
+__device__ __forceinline__ BlockLds<NW>& block_lds() {
+  __shared__ BlockLds<NW> g;
+  return g;
+}
 
 // generic single-problem entry (evh_find_homography_ransac)
-__global__ __launch_bounds__(64) void k_find_homography(EvhRansacArgs A) {
-  RansacLds& S = g_lds;
-  const int lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(NW * NL) void k_find_homography(EvhRansacArgs A) {
+  BlockLds<NW>& B = block_lds<NW>();
+  const int tid = threadIdx.x;
   const int n = A.n_fixed;
-  bool found = find_homography_wave(S, lane, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.lm,
-                                    A.info);
-  WSYNC();
-  if (lane < 9) A.H[lane] = found ? S.H[lane] : 0.0;
-  if (lane == 0) A.found[0] = found ? 1 : 0;
+  const bool found = find_homography_block<NW>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info);
+  if (tid < 9) A.H[tid] = found ? B.s.H[tid] : 0.0;
+  if (tid == 0) A.found[0] = found ? 1 : 0;
 }
 
 // generic static filter entry
-__global__ __launch_bounds__(64) void k_static_filter(const double* H, const float* rows, int n, int* rbin, float* out,
-                                                      int* count) {
-  __shared__ double Hs[9];
-  const int lane = threadIdx.x;
-  if (lane < 9) Hs[lane] = H[lane];
-  WSYNC();
-  int m = static_filter_wave(lane, Hs, rows, n, rbin, out);
-  if (lane == 0) count[0] = m;
+template <int NW>
+__global__ __launch_bounds__(NW * NL) void k_static_filter(const double* H, const float* rows, int n, int* rbin,
+                                                           float* out, int* count) {
+  BlockLds<NW>& B = block_lds<NW>();
+  const int tid = threadIdx.x;
+  if (tid < 9) B.s.H[tid] = H[tid];
+  __syncthreads();
+  const int m = static_filter_block<NW>(B, B.s.H, rows, n, rbin, out);
+  if (tid == 0) count[0] = m;
 }
 
 // phase 1 of a pair: RANSAC #1 on the matched rows, then the static-point filter (matching.py:152-163)
-__global__ __launch_bounds__(64) void k_ransac_static(EvhRansacArgs A) {
-  RansacLds& S = g_lds;
-  const int p = blockIdx.x, lane = threadIdx.x;
-  if (A.status[p] != EVH_PAIR_OK) { if (lane == 0) A.npts2[p] = 0; return; }
+template <int NW>
+__global__ __launch_bounds__(NW * NL) void k_ransac_static(EvhRansacArgs A) {
+  BlockLds<NW>& B = block_lds<NW>();
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (A.status[p] != EVH_PAIR_OK) { if (tid == 0) A.npts2[p] = 0; return; }
   const int n = A.npts[p];
   const float* rows = A.pts + (int64_t)p * A.row_stride * 4;
   float* out = A.pts2 + (int64_t)p * A.row_stride * 4;
   uint8_t* mask = A.mask + (int64_t)p * A.row_stride;
   float* crow = A.crow + (int64_t)p * A.row_stride * 4;
-  double* lm = A.lm + (int64_t)p * A.row_stride * 4;
+  int* rbin = reinterpret_cast<int*>(A.lm + (int64_t)p * A.row_stride * 4);
   int* info = A.info ? A.info + 8 * p : nullptr;
-  bool found = find_homography_wave(S, lane, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, lm, info);
-  WSYNC();
+  const bool found = find_homography_block<NW>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info);
   if (!found) {
-    if (lane == 0) { A.status[p] = EVH_PAIR_NO_PROVISIONAL_H; A.npts2[p] = 0; }
+    if (tid == 0) { A.status[p] = EVH_PAIR_NO_PROVISIONAL_H; A.npts2[p] = 0; }
     return;
   }
-  if (A.H1 && lane < 9) A.H1[9 * p + lane] = S.H[lane];
-  int* rbin = reinterpret_cast<int*>(lm);  // LM scratch is free again
-  int m = static_filter_wave(lane, S.H, rows, n, rbin, out);
-  if (lane == 0) A.npts2[p] = m;
+  if (A.H1 && tid < 9) A.H1[9 * p + tid] = B.s.H[tid];
+  const int m = static_filter_block<NW>(B, B.s.H, rows, n, rbin, out);
+  if (tid == 0) A.npts2[p] = m;
 }
 
-// phase 2: compute_homography.  Independent pairs: one wave per pair, Hsup = None.
-__global__ __launch_bounds__(64) void k_ransac_final_pairs(EvhRansacArgs A) {
-  RansacLds& S = g_lds;
-  const int p = blockIdx.x, lane = threadIdx.x;
+// phase 2: compute_homography.  Independent pairs: one workgroup per pair, Hsup = None.
+template <int NW>
+__global__ __launch_bounds__(NW * NL) void k_ransac_final_pairs(EvhRansacArgs A) {
+  BlockLds<NW>& B = block_lds<NW>();
+  const int p = blockIdx.x, tid = threadIdx.x;
   int st = A.status[p];
   if (st == EVH_PAIR_OK) {
     const int n = A.npts2[p];
     const float* rows = A.pts2 + (int64_t)p * A.row_stride * 4;
-    st = compute_homography_wave(S, lane, rows, n, nullptr, A, A.mask + (int64_t)p * A.row_stride,
-                                 A.pts + (int64_t)p * A.row_stride * 4 /* matched rows are dead: reuse as scratch */,
-                                 A.crow + (int64_t)p * A.row_stride * 4, A.lm + (int64_t)p * A.row_stride * 4,
-                                 A.info ? A.info + 8 * p + 4 : nullptr);
+    st = compute_homography_block<NW>(B, rows, n, nullptr, A, A.mask + (int64_t)p * A.row_stride,
+                                      A.pts + (int64_t)p * A.row_stride * 4 /* matched rows are dead: scratch */,
+                                      A.crow + (int64_t)p * A.row_stride * 4, A.info ? A.info + 8 * p + 4 : nullptr);
   }
-  WSYNC();
-  if (lane < 9) A.H[9 * p + lane] = st == EVH_PAIR_OK ? S.H[lane] : 0.0;
-  if (lane == 0) A.out_status[p] = st;
+  if (tid < 9) A.H[9 * p + tid] = st == EVH_PAIR_OK ? B.s.H[tid] : 0.0;
+  if (tid == 0) A.out_status[p] = st;
 }
 
 // phase 2, stream semantics (video_processing.py:83-105): sequential scan over the pairs of one stream with the
 // running superposition; a failed pair repeats the previous H (none_H_processing=True).
-__global__ __launch_bounds__(64) void k_ransac_final_stream(EvhRansacArgs A, int npairs, int pitch) {
-  // one wavefront per stream: block s scans the npairs pairs whose per-pair slots start at s * pitch (several streams
+template <int NW>
+__global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A, int npairs, int pitch) {
+  // one workgroup per stream: block s scans the npairs pairs whose per-pair slots start at s * pitch (several streams
   // of one batch sit `pitch` pair slots apart); H / status are written compactly at s * npairs + p
-  RansacLds& S = g_lds;
-  __shared__ double Hsup[9], Hprev[9], Hcur[9];
-  __shared__ int have_prev;
-  const int lane = threadIdx.x, s = blockIdx.x;
+  BlockLds<NW>& B = block_lds<NW>();
+  const int tid = threadIdx.x, s = blockIdx.x;
   const double* Hsup0 = A.Hsup0 ? A.Hsup0 + 18 * s : nullptr;
   const double* Hprev0 = A.Hprev0 ? A.Hprev0 + 18 * s : nullptr;
   const int64_t slot0 = (int64_t)s * pitch;                 // first pair slot of this stream; also its scratch slot
   double* Hout = A.H + (int64_t)9 * s * npairs;
   int* stout = A.out_status + (int64_t)s * npairs;
-  if (lane == 0) have_prev = Hprev0 ? 1 : 0;
-  if (lane < 9 && Hsup0) Hsup[lane] = Hsup0[lane];
-  if (lane < 9 && Hprev0) Hprev[lane] = Hprev0[lane];
-  WSYNC();
+  if (tid == 0) B.have_prev = Hprev0 ? 1 : 0;
+  if (tid < 9 && Hsup0) B.Hsup[tid] = Hsup0[tid];
+  if (tid < 9 && Hprev0) B.Hprev[tid] = Hprev0[tid];
+  __syncthreads();
   bool first = Hsup0 == nullptr;
   for (int p = 0; p < npairs; p++) {
     int st = A.status[slot0 + p];
@@ -920,62 +1092,78 @@ __global__ __launch_bounds__(64) void k_ransac_final_stream(EvhRansacArgs A, int
       const int n = A.npts2[slot0 + p];
       const float* rows = A.pts2 + (slot0 + p) * A.row_stride * 4;
       // the scan is sequential: one pair's worth of scratch (the stream's first slot) serves all its pairs
-      st = compute_homography_wave(S, lane, rows, n, first ? nullptr : Hsup, A, A.mask + slot0 * A.row_stride,
-                                   A.pts + slot0 * A.row_stride * 4, A.crow + slot0 * A.row_stride * 4,
-                                   A.lm + slot0 * A.row_stride * 4, A.info ? A.info + 8 * (slot0 + p) + 4 : nullptr);
+      st = compute_homography_block<NW>(B, rows, n, first ? nullptr : B.Hsup, A, A.mask + slot0 * A.row_stride,
+                                        A.pts + slot0 * A.row_stride * 4, A.crow + slot0 * A.row_stride * 4,
+                                        A.info ? A.info + 8 * (slot0 + p) + 4 : nullptr);
     }
-    WSYNC();
-    if (lane == 0) stout[p] = st;
-    if (st != EVH_PAIR_OK && !have_prev) {
+    if (tid == 0) stout[p] = st;
+    if (st != EVH_PAIR_OK && !B.have_prev) {
       // the reference raises here (None.tolist()); mark the pair and stop the scan
-      if (lane < 9) Hout[9 * p + lane] = __longlong_as_double(0x7FF8000000000000ll);
-      for (int q = p + 1 + lane; q < npairs; q += NL) { stout[q] = st; }
-      for (int q = p + 1; q < npairs; q++) if (lane < 9) Hout[9 * q + lane] = __longlong_as_double(0x7FF8000000000000ll);
+      const double nan = __longlong_as_double(0x7FF8000000000000ll);
+      for (int q = p + 1 + tid; q < npairs; q += NW * NL) stout[q] = st;
+      for (int q = 9 * p + tid; q < 9 * npairs; q += NW * NL) Hout[q] = nan;
       return;
     }
-    if (lane < 9) Hcur[lane] = st == EVH_PAIR_OK ? S.H[lane] : Hprev[lane];
-    WSYNC();
-    if (lane < 9) { Hout[9 * p + lane] = Hcur[lane]; Hprev[lane] = Hcur[lane]; }
-    // matrix_superposition (utils.py:139-145); np.dot(3x3,3x3) = forward FMA chain (pinned by fixtures)
-    double P = 0;
-    if (!first && lane < 9) {
-      const int r = lane / 3, c = lane - 3 * r;
-      P = fma(Hcur[3 * r + 2], Hsup[6 + c], fma(Hcur[3 * r + 1], Hsup[3 + c], Hcur[3 * r] * Hsup[c]));
+    if (tid < 9) B.Hcur[tid] = st == EVH_PAIR_OK ? B.s.H[tid] : B.Hprev[tid];
+    __syncthreads();
+    if (tid < NL) {                          // wave 0
+      if (tid < 9) { Hout[9 * p + tid] = B.Hcur[tid]; B.Hprev[tid] = B.Hcur[tid]; }
+      // matrix_superposition (utils.py:139-145); np.dot(3x3,3x3) = forward FMA chain (pinned by fixtures)
+      double P = 0;
+      if (!first && tid < 9) {
+        const int r = tid / 3, c = tid - 3 * r;
+        P = fma(B.Hcur[3 * r + 2], B.Hsup[6 + c], fma(B.Hcur[3 * r + 1], B.Hsup[3 + c], B.Hcur[3 * r] * B.Hsup[c]));
+      }
+      const double P8 = __shfl(P, 8);
+      WSYNC();
+      if (tid < 9) B.Hsup[tid] = first ? B.Hcur[tid] : P / P8;
+      if (tid == 0) B.have_prev = 1;
     }
-    const double P8 = __shfl(P, 8);
-    WSYNC();
-    if (lane < 9) Hsup[lane] = first ? Hcur[lane] : P / P8;
-    if (lane == 0) have_prev = 1;
     first = false;
-    WSYNC();
+    __syncthreads();
   }
-  if (A.state_out && lane < 9) { A.state_out[18 * s + lane] = Hsup[lane]; A.state_out[18 * s + 9 + lane] = Hprev[lane]; }
+  if (A.state_out && tid < 9) { A.state_out[18 * s + tid] = B.Hsup[tid]; A.state_out[18 * s + 9 + tid] = B.Hprev[tid]; }
+}
+
+// waves per workgroup: enough rows to cover the handful of hypotheses an adaptive RANSAC needs in one chunk when the
+// launch is small (latency), one wave per pair when the launch fills the chip anyway (throughput), sixteen when the
+// caller forces all 2000 iterations
+int waves_for(int nblocks, int force_max) {
+  if (force_max) return 16;
+  return nblocks >= 512 ? 1 : 4;
 }
 
 }  // namespace
 
+#define EVH_LAUNCH_NW(nw, kernel, grid, stream, ...)                                                     \
+  do {                                                                                                  \
+    if ((nw) == 16) hipLaunchKernelGGL(kernel<16>, dim3(grid), dim3(16 * NL), 0, stream, __VA_ARGS__);   \
+    else if ((nw) == 4) hipLaunchKernelGGL(kernel<4>, dim3(grid), dim3(4 * NL), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel<1>, dim3(grid), dim3(NL), 0, stream, __VA_ARGS__);                    \
+  } while (0)
+
 int evh_launch_find_homography(evh_ctx* c, const EvhRansacArgs& A) {
-  hipLaunchKernelGGL(k_find_homography, dim3(1), dim3(64), 0, c->stream, A);
+  EVH_LAUNCH_NW(waves_for(1, A.force_max), k_find_homography, 1, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
 int evh_launch_static_filter(evh_ctx* c, const double* d_H, const float* d_rows, int n, int* d_rbin, float* d_out,
                              int* d_count) {
-  hipLaunchKernelGGL(k_static_filter, dim3(1), dim3(64), 0, c->stream, d_H, d_rows, n, d_rbin, d_out, d_count);
+  hipLaunchKernelGGL(k_static_filter<4>, dim3(1), dim3(4 * NL), 0, c->stream, d_H, d_rows, n, d_rbin, d_out, d_count);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
 int evh_launch_ransac_static(evh_ctx* c, const EvhRansacArgs& A, int npairs) {
   if (npairs <= 0) return EVH_SUCCESS;
-  hipLaunchKernelGGL(k_ransac_static, dim3(npairs), dim3(64), 0, c->stream, A);
+  EVH_LAUNCH_NW(waves_for(npairs, A.force_max), k_ransac_static, npairs, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
 int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A, int npairs, int nstreams, int pitch) {
   if (npairs <= 0) return EVH_SUCCESS;
   // nstreams == 0: independent pairs; otherwise nstreams sequential scans of npairs pairs each, `pitch` pair slots apart
-  if (nstreams > 0) hipLaunchKernelGGL(k_ransac_final_stream, dim3(nstreams), dim3(64), 0, c->stream, A, npairs, pitch);
-  else hipLaunchKernelGGL(k_ransac_final_pairs, dim3(npairs), dim3(64), 0, c->stream, A);
+  if (nstreams > 0) EVH_LAUNCH_NW(waves_for(nstreams, A.force_max), k_ransac_final_stream, nstreams, c->stream, A, npairs, pitch);
+  else EVH_LAUNCH_NW(waves_for(npairs, A.force_max), k_ransac_final_pairs, npairs, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
