@@ -51,6 +51,7 @@ SIGNATURES = {
     "evh_match_knn2_hamming": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "evh_ratio_unique_filter": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _i, _vp, _pi, _pi]),
     "evh_find_homography_ransac": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _vp, _pi, _vp]),
+    "evh_find_homography_ransac_fixed": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _vp, _pi, _vp]),
     "evh_static_filter": (_i, [_vp, _vp, _vp, _i, _vp, _pi]),
     "evh_pair_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp]),
     "evh_stream_homography_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
@@ -246,13 +247,13 @@ class Context:
         return n.value, st.value
 
     # ---- K8/K9 ----
-    def find_homography(self, pts, thr=3.0, max_iters=2000, conf=0.995):
+    def find_homography(self, pts, thr=3.0, max_iters=2000, conf=0.995, force_max_iters=False):
         n = pts.shape[0]
         H = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8); info = np.zeros(3, np.int32)
         found = C.c_int()
-        self._check(self.lib.evh_find_homography_ransac(self.h, pts.data_ptr() if n else None, n, float(thr),
-                                                        int(max_iters), float(conf), _hp(H), _hp(mask), C.byref(found),
-                                                        _hp(info)))
+        f = self.lib.evh_find_homography_ransac_fixed if force_max_iters else self.lib.evh_find_homography_ransac
+        self._check(f(self.h, pts.data_ptr() if n else None, n, float(thr), int(max_iters), float(conf), _hp(H),
+                      _hp(mask), C.byref(found), _hp(info)))
         return (H.reshape(3, 3) if found.value else None), mask[:n].copy(), info
 
     def static_filter(self, H, pts, out):

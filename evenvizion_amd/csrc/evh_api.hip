@@ -541,15 +541,15 @@ int evh_ratio_unique_filter(evh_ctx* c, const int32_t* d_idx, const uint32_t* d_
   return EVH_SUCCESS;
 }
 
-int evh_find_homography_ransac(evh_ctx* c, const float* d_pts, int n, double thr, int max_iters, double conf, double* h_H,
-                               uint8_t* h_mask, int* h_found, int* h_info) {
+static int find_homography_entry(evh_ctx* c, const float* d_pts, int n, double thr, int max_iters, double conf, int force_max,
+                                 double* h_H, uint8_t* h_mask, int* h_found, int* h_info) {
   if (!c || (!d_pts && n > 0) || n < 0 || !h_H || !h_found) return evh_fail(c, EVH_ERR_INVALID, "evh_find_homography_ransac: bad argument");
   if (n > c->kcap * c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "evh_find_homography_ransac: too many rows");
   if (((uintptr_t)d_pts) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_pts must be 16-byte aligned");
   { int jr = join_solve(c); if (jr) return jr; }
   // scratch: the per-pair buffers viewed as one big problem
   EvhRansacArgs R{};
-  R.pts = const_cast<float*>(d_pts); R.n_fixed = n; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = 0;
+  R.pts = const_cast<float*>(d_pts); R.n_fixed = n; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = force_max;
   R.mask = c->d_mask; R.crow = c->d_crow; R.lm = c->d_lm;
   R.H = c->d_small; R.found = reinterpret_cast<int*>(c->d_small + 16); R.info = reinterpret_cast<int*>(c->d_small + 17);
   int rc = evh_launch_find_homography(c, R);
@@ -564,6 +564,15 @@ int evh_find_homography_ransac(evh_ctx* c, const float* d_pts, int n, double thr
   *h_found = found;
   if (h_info) memcpy(h_info, info, sizeof(info));
   return EVH_SUCCESS;
+}
+
+int evh_find_homography_ransac(evh_ctx* c, const float* d_pts, int n, double thr, int max_iters, double conf, double* h_H,
+                               uint8_t* h_mask, int* h_found, int* h_info) {
+  return find_homography_entry(c, d_pts, n, thr, max_iters, conf, 0, h_H, h_mask, h_found, h_info);
+}
+int evh_find_homography_ransac_fixed(evh_ctx* c, const float* d_pts, int n, double thr, int max_iters, double conf,
+                                     double* h_H, uint8_t* h_mask, int* h_found, int* h_info) {
+  return find_homography_entry(c, d_pts, n, thr, max_iters, conf, 1, h_H, h_mask, h_found, h_info);
 }
 
 int evh_static_filter(evh_ctx* c, const double* h_H, const float* d_pts, int n, float* d_out_pts, int* h_count) {

@@ -153,6 +153,11 @@ int evh_ratio_unique_filter(evh_ctx* ctx, const int32_t* d_idx, const uint32_t* 
  * h_found 0/1, h_info i32[3] = {ransac iterations, best inlier count, LM iterations} (may be NULL).           */
 int evh_find_homography_ransac(evh_ctx* ctx, const float* d_pts, int n, double thr, int max_iters, double conf,
                                double* h_H, uint8_t* h_mask, int* h_found, int* h_info);
+/* The same with the iteration bound held fixed: exactly max(max_iters, 1) accepted samples are evaluated (the
+ * adaptive bound RANSACUpdateNumIters is not applied).  This is the force_max_iters mode of the fused entries below
+ * -- the fixed-iteration workload of BASELINE.json configs[2] -- exposed for one point set.                       */
+int evh_find_homography_ransac_fixed(evh_ctx* ctx, const float* d_pts, int n, double thr, int max_iters, double conf,
+                                     double* h_H, uint8_t* h_mask, int* h_found, int* h_info);
 /* find_point_displacement + get_largest_group_points: rows of the most populated rounded-displacement bin */
 int evh_static_filter(evh_ctx* ctx, const double* h_H, const float* d_pts, int n, float* d_out_pts, int* h_count);
 

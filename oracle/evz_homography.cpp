@@ -462,8 +462,10 @@ int lm_refine(const float* M, const float* m, int count, double* H) {
 
 }  // namespace
 
-extern "C" int evo_find_homography(const float* a, const float* b, int n, double thr, int maxItersArg, double conf,
-                                   double* H, uint8_t* mask, int* info) {
+/* force_max != 0: the iteration bound is never lowered (RANSACUpdateNumIters is not called), i.e. exactly
+ * max(maxItersArg, 1) accepted samples are evaluated -- the fixed-iteration workload of BASELINE configs[2]. */
+extern "C" int evo_find_homography_ex(const float* a, const float* b, int n, double thr, int maxItersArg, double conf,
+                                      int force_max, double* H, uint8_t* mask, int* info) {
   int it_run = 0, best = 0, lm_it = 0;
   bool result = false;
   if (info) info[0] = info[1] = info[2] = 0;
@@ -493,7 +495,7 @@ extern "C" int evo_find_homography(const float* a, const float* b, int n, double
         memcpy(mask, cur.data(), n);
         memcpy(bestModel, model, sizeof(model));
         maxGood = good;
-        niters = update_num_iters(conf, (double)(n - good) / n, 4, niters);
+        if (!force_max) niters = update_num_iters(conf, (double)(n - good) / n, 4, niters);
       }
     }
     best = maxGood;
@@ -512,6 +514,11 @@ extern "C" int evo_find_homography(const float* a, const float* b, int n, double
   }
   if (info) info[2] = lm_it;
   return 1;
+}
+
+extern "C" int evo_find_homography(const float* a, const float* b, int n, double thr, int maxItersArg, double conf,
+                                   double* H, uint8_t* mask, int* info) {
+  return evo_find_homography_ex(a, b, n, thr, maxItersArg, conf, 0, H, mask, info);
 }
 
 /* np.dot(H, (x, y, 1)): the summation order of numpy's BLAS matrix-vector kernel as captured in
@@ -556,7 +563,8 @@ static inline void htransform(const double* H, double x, double y, double* ox, d
 }
 
 /* compute_homography (utils.py:351-362) */
-extern "C" int evo_compute_homography(const float* a, const float* b, int n, const double* Hsup, double* H) {
+extern "C" int evo_compute_homography_ex(const float* a, const float* b, int n, const double* Hsup, int force_max,
+                                         double* H) {
   std::vector<float> fa(a, a + 2 * n), fb(b, b + 2 * n);
   if (Hsup) {
     for (int i = 0; i < n; i++) {
@@ -566,12 +574,16 @@ extern "C" int evo_compute_homography(const float* a, const float* b, int n, con
     }
   }
   std::vector<uint8_t> mask(n > 0 ? n : 1);
-  int found = evo_find_homography(fa.data(), fb.data(), n, 3.0, 2000, 0.995, H, mask.data(), nullptr);
+  int found = evo_find_homography_ex(fa.data(), fb.data(), n, 3.0, 2000, 0.995, force_max, H, mask.data(), nullptr);
   int s = 0;
   for (int i = 0; i < n; i++) s += mask[i];
   if ((double)s < 0.7 * (double)n) return EVO_LOW_INLIER_RATIO;
   if (!found) return EVO_NO_FINAL_H;
   return EVO_OK;
+}
+
+extern "C" int evo_compute_homography(const float* a, const float* b, int n, const double* Hsup, double* H) {
+  return evo_compute_homography_ex(a, b, n, Hsup, 0, H);
 }
 
 /* matrix_superposition (utils.py:139-145) */
@@ -585,8 +597,8 @@ extern "C" void evo_matrix_superposition(const double* H, const double* Hsup, in
 }
 
 /* KeyPoints.match_static_kps (matching.py:131-163); a = self (current frame), b = acceding (previous) */
-extern "C" int evo_match_static(const float* xy_a, const uint8_t* desc_a, int na, const float* xy_b,
-                                const uint8_t* desc_b, int nb, float* oa, float* ob, int* out_n) {
+extern "C" int evo_match_static_ex(const float* xy_a, const uint8_t* desc_a, int na, const float* xy_b,
+                                   const uint8_t* desc_b, int nb, int force_max, float* oa, float* ob, int* out_n) {
   *out_n = 0;
   if (na == 0 || nb == 0) return EVO_NO_DESCRIPTORS;
   std::vector<int32_t> idx(2 * na), mq(na), mt(na);
@@ -602,10 +614,14 @@ extern "C" int evo_match_static(const float* xy_a, const uint8_t* desc_a, int na
   int u = evo_remove_double(pa.data(), pb.data(), m, ua.data(), ub.data());
   double H[9];
   std::vector<uint8_t> mask(u);
-  if (!evo_find_homography(ua.data(), ub.data(), u, 3.0, 2000, 0.995, H, mask.data(), nullptr))
+  if (!evo_find_homography_ex(ua.data(), ub.data(), u, 3.0, 2000, 0.995, force_max, H, mask.data(), nullptr))
     return EVO_NO_PROVISIONAL_H;
   *out_n = evo_static_filter(H, ua.data(), ub.data(), u, oa, ob);
   return EVO_OK;
+}
+extern "C" int evo_match_static(const float* xy_a, const uint8_t* desc_a, int na, const float* xy_b,
+                                const uint8_t* desc_b, int nb, float* oa, float* ob, int* out_n) {
+  return evo_match_static_ex(xy_a, desc_a, na, xy_b, desc_b, nb, 0, oa, ob, out_n);
 }
 
 namespace {
@@ -617,15 +633,15 @@ void detect(const uint8_t* gray, int w, int h, int nfeatures, Feat& f) {
   f.n = evo_orb_detect(gray, w, h, nfeatures, f.xy.data(), f.desc.data(), oc.data(), lx.data(), ly.data(), rs.data(),
                        an.data(), cap);
 }
-int pair_from_feats(const Feat& cur, const Feat& prev, const double* Hsup, double* H) {
+int pair_from_feats(const Feat& cur, const Feat& prev, const double* Hsup, double* H, int force_max = 0) {
   std::vector<float> oa(2 * std::max(cur.n, 1)), ob(2 * std::max(cur.n, 1)), ua(oa.size()), ub(oa.size());
   int n = 0;
-  int st = evo_match_static(cur.xy.data(), cur.desc.data(), cur.n, prev.xy.data(), prev.desc.data(), prev.n, oa.data(),
-                            ob.data(), &n);
+  int st = evo_match_static_ex(cur.xy.data(), cur.desc.data(), cur.n, prev.xy.data(), prev.desc.data(), prev.n,
+                               force_max, oa.data(), ob.data(), &n);
   if (st != EVO_OK) return st;
   // frame_processing.py:102-104: remove_double_matching across feature types (single type here)
   int u = evo_remove_double(oa.data(), ob.data(), n, ua.data(), ub.data());
-  return evo_compute_homography(ua.data(), ub.data(), u, Hsup, H);
+  return evo_compute_homography_ex(ua.data(), ub.data(), u, Hsup, force_max, H);
 }
 }  // namespace
 
@@ -651,7 +667,8 @@ extern "C" void evo_pairs_gray_batch(const uint8_t* frames, int npairs, int w, i
   for (auto& x : th) x.join();
 }
 
-extern "C" int evo_stream_gray(const uint8_t* frames, int nframes, int w, int h, int nfeatures, double* H, int* status) {
+extern "C" int evo_stream_gray_ex(const uint8_t* frames, int nframes, int w, int h, int nfeatures, int force_max,
+                                  double* H, int* status) {
   size_t fs = (size_t)w * h;
   Feat prev, cur;
   detect(frames, w, h, nfeatures, prev);
@@ -660,7 +677,7 @@ extern "C" int evo_stream_gray(const uint8_t* frames, int nframes, int w, int h,
   for (int k = 1; k < nframes; k++) {
     detect(frames + (size_t)k * fs, w, h, nfeatures, cur);
     double* Hk = H + 9 * (size_t)(k - 1);
-    int st = pair_from_feats(cur, prev, first ? nullptr : Hsup, Hk);
+    int st = pair_from_feats(cur, prev, first ? nullptr : Hsup, Hk, force_max);
     status[k - 1] = st;
     if (st != EVO_OK) {
       if (!have_prev) return k - 1;  // reference: None.tolist() raises on a failing first pair
@@ -674,4 +691,7 @@ extern "C" int evo_stream_gray(const uint8_t* frames, int nframes, int w, int h,
     std::swap(prev, cur);
   }
   return -1;
+}
+extern "C" int evo_stream_gray(const uint8_t* frames, int nframes, int w, int h, int nfeatures, double* H, int* status) {
+  return evo_stream_gray_ex(frames, nframes, w, h, nfeatures, 0, H, status);
 }

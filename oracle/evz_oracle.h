@@ -70,6 +70,10 @@ int evo_remove_double(const float* a, const float* b, int n, float* oa, float* o
 /* returns 1 when H found. info[0]=ransac iterations executed, info[1]=best inlier count, info[2]=LM iters */
 int evo_find_homography(const float* a, const float* b, int n, double thr, int max_iters, double conf,
                         double* H, uint8_t* mask, int* info);
+/* the same with force_max != 0: the iteration bound is never lowered -- all max(max_iters, 1) accepted samples are
+ * evaluated (the fixed-iteration RANSAC of BASELINE configs[2]; not a reference mode, a stress variant of it) */
+int evo_find_homography_ex(const float* a, const float* b, int n, double thr, int max_iters, double conf,
+                           int force_max, double* H, uint8_t* mask, int* info);
 /* building blocks exposed for tests */
 int evo_dlt(const float* src, const float* dst, int n, double* H);
 void evo_jacobi(double* A, int n, double* W, double* V);
@@ -79,6 +83,7 @@ void evo_jacobi(double* A, int n, double* W, double* V);
 int evo_static_filter(const double* H, const float* a, const float* b, int n, float* oa, float* ob);
 /* compute_homography incl. optional pre-transform by Hsup (NULL = None). returns status (EVO_*) */
 int evo_compute_homography(const float* a, const float* b, int n, const double* Hsup, double* H);
+int evo_compute_homography_ex(const float* a, const float* b, int n, const double* Hsup, int force_max, double* H);
 /* matrix_superposition (utils.py:118-145) */
 void evo_matrix_superposition(const double* H, const double* Hsup, int first, double* out);
 
@@ -86,6 +91,8 @@ void evo_matrix_superposition(const double* H, const double* Hsup, int first, do
 /* KeyPoints.match_static_kps from two keypoint sets; returns status, static points in oa/ob (cap = nq) */
 int evo_match_static(const float* xy_a, const uint8_t* desc_a, int na, const float* xy_b, const uint8_t* desc_b,
                      int nb, float* oa, float* ob, int* out_n);
+int evo_match_static_ex(const float* xy_a, const uint8_t* desc_a, int na, const float* xy_b, const uint8_t* desc_b,
+                        int nb, int force_max, float* oa, float* ob, int* out_n);
 /* one frame pair from gray frames: cur = current frame (a), prev = previous frame (b) */
 int evo_pair_gray(const uint8_t* cur, const uint8_t* prev, int w, int h, int nfeatures, const double* Hsup,
                   double* H);
@@ -96,6 +103,8 @@ void evo_pairs_gray_batch(const uint8_t* frames, int npairs, int w, int h, int n
  * none_H_processing=True). H: [F-1][9]; status: [F-1]; a failed first pair yields status and stops (returns
  * the index of the failing pair, or -1 when all pairs were processed). */
 int evo_stream_gray(const uint8_t* frames, int nframes, int w, int h, int nfeatures, double* H, int* status);
+int evo_stream_gray_ex(const uint8_t* frames, int nframes, int w, int h, int nfeatures, int force_max, double* H,
+                       int* status);
 
 #ifdef __cplusplus
 }

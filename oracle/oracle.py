@@ -177,14 +177,15 @@ def remove_double(a, b):
     return oa[:m].copy(), ob[:m].copy()
 
 
-def find_homography(a, b, thr=3.0, max_iters=2000, conf=0.995):
+def find_homography(a, b, thr=3.0, max_iters=2000, conf=0.995, force_max_iters=False):
     """-> (H f64[3,3] or None, mask u8[n], info)"""
     a = _f32(a).reshape(-1, 2); b = _f32(b).reshape(-1, 2)
     n = len(a)
     H = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8); info = np.zeros(3, np.int32)
-    f = lib().evo_find_homography
-    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
-    ok = f(_p(a), _p(b), n, float(thr), int(max_iters), float(conf), _p(H), _p(mask), _p(info))
+    f = lib().evo_find_homography_ex
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                  C.c_void_p]
+    ok = f(_p(a), _p(b), n, float(thr), int(max_iters), float(conf), int(bool(force_max_iters)), _p(H), _p(mask), _p(info))
     return (H.reshape(3, 3) if ok else None), mask[:n].copy(), info
 
 
@@ -211,12 +212,13 @@ def static_filter(H, a, b):
     return oa[:m].copy(), ob[:m].copy()
 
 
-def compute_homography(a, b, Hsup=None):
+def compute_homography(a, b, Hsup=None, force_max_iters=False):
     """-> (status, H f64[3,3])"""
     a = _f32(a).reshape(-1, 2); b = _f32(b).reshape(-1, 2)
     H = np.zeros(9, np.float64)
     hs = None if Hsup is None else np.ascontiguousarray(Hsup, np.float64).reshape(9)
-    st = lib().evo_compute_homography(_p(a), _p(b), len(a), None if hs is None else _p(hs), _p(H))
+    st = lib().evo_compute_homography_ex(_p(a), _p(b), len(a), None if hs is None else _p(hs),
+                                         int(bool(force_max_iters)), _p(H))
     return st, H.reshape(3, 3)
 
 
@@ -258,10 +260,10 @@ def pairs_gray_batch(frames, nfeatures=500, threads=1):
     return H.reshape(nb, 3, 3), st
 
 
-def stream_gray(frames, nfeatures=500):
+def stream_gray(frames, nfeatures=500, force_max_iters=False):
     """frames u8[F,h,w] -> (H f64[F-1,3,3], status i32[F-1], failed_first_pair_index or -1)"""
     frames = _u8(frames)
     nf, h, w = frames.shape
     H = np.zeros((nf - 1, 9), np.float64); st = np.zeros(nf - 1, np.int32)
-    rc = lib().evo_stream_gray(_p(frames), nf, w, h, nfeatures, _p(H), _p(st))
+    rc = lib().evo_stream_gray_ex(_p(frames), nf, w, h, nfeatures, int(bool(force_max_iters)), _p(H), _p(st))
     return H.reshape(-1, 3, 3), st, rc
