@@ -128,6 +128,11 @@ class Context:
         except Exception:
             pass
 
+    def _enter(self):
+        """Order this context's (non-blocking) stream behind the work already queued on torch's current stream: the
+        tensors a call receives may still be being filled there (torch.zeros, copies, a previous op's output)."""
+        self.order_after_torch()
+
     def _check(self, rc):
         if rc < 0:
             raise EvhError("libevhip error %d: %s" % (rc, self.lib.evh_last_error_string(self.h).decode()))
@@ -159,6 +164,7 @@ class Context:
     # ---- K0 ----
     def resize_area(self, src, dst):
         """src/dst: CUDA uint8 tensors [n,h,w] or [n,h,w,c], contiguous."""
+        self._enter()
         n, sh, sw = src.shape[:3]
         cn = 1 if src.dim() == 3 else src.shape[3]
         dh, dw = dst.shape[1:3]
@@ -167,6 +173,7 @@ class Context:
 
     def resize_area_bgr(self, src, dst):
         """One BGR image: src CUDA uint8 [sh,sw,3] -> dst [dh,dw,3] (imutils.resize / INTER_AREA)."""
+        self._enter()
         sh, sw = src.shape[:2]; dh, dw = dst.shape[:2]
         self._check(self.lib.evh_resize_area_u8c3(self.h, src.data_ptr(), sw, sh, dst.data_ptr(), dw, dh))
 
@@ -190,6 +197,7 @@ class Context:
     # ---- K1..K6 ----
     def orb_detect_batch(self, frames, nfeatures=500):
         """frames: CUDA uint8 tensor [n,h,w] (gray) or [n,h,w,3] (BGR), contiguous."""
+        self._enter()
         n, h, w = frames.shape[:3]
         cn = 1 if frames.dim() == 3 else frames.shape[3]
         self._check(self.lib.evh_orb_detect_batch(self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures))
@@ -197,6 +205,7 @@ class Context:
     def orb_detect_compute(self, frame, nfeatures=500):
         """One frame (CUDA uint8 [h,w] or [h,w,3]) -> (xy f32[n,2], desc u8[n,32], octave i32[n]); the single-frame
         form of cv2.ORB_create().detectAndCompute (frame_processing.py:60-61)."""
+        self._enter()
         h, w = frame.shape[:2]
         cn = 1 if frame.dim() == 2 else frame.shape[2]
         cap = self.lib.evh_orb_capacity(self.h)
@@ -236,10 +245,12 @@ class Context:
 
     # ---- K7 + glue ----
     def knn2(self, q, t, idx, d2, hamming=False):
+        self._enter()
         f = self.lib.evh_match_knn2_hamming if hamming else self.lib.evh_match_knn2_l2u8
         self._check(f(self.h, q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0], idx.data_ptr(), d2.data_ptr()))
 
     def ratio_unique_filter(self, idx, d2, xy_q, xy_t, pts, ratio=0.5, min_matches=4):
+        self._enter()
         n = C.c_int(); st = C.c_int()
         self._check(self.lib.evh_ratio_unique_filter(self.h, idx.data_ptr(), d2.data_ptr(), idx.shape[0], xy_t.shape[0],
                                                      xy_q.data_ptr(), xy_t.data_ptr(), float(ratio), int(min_matches),
@@ -248,6 +259,7 @@ class Context:
 
     # ---- K8/K9 ----
     def find_homography(self, pts, thr=3.0, max_iters=2000, conf=0.995, force_max_iters=False):
+        self._enter()
         n = pts.shape[0]
         H = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8); info = np.zeros(3, np.int32)
         found = C.c_int()
@@ -257,6 +269,7 @@ class Context:
         return (H.reshape(3, 3) if found.value else None), mask[:n].copy(), info
 
     def static_filter(self, H, pts, out):
+        self._enter()
         H = np.ascontiguousarray(H, np.float64).reshape(9)
         n = C.c_int()
         self._check(self.lib.evh_static_filter(self.h, _hp(H), pts.data_ptr(), pts.shape[0], out.data_ptr(), C.byref(n)))
@@ -265,6 +278,7 @@ class Context:
     # ---- fused ----
     def pair_homography_batch(self, frames, npairs, mode, out_H, out_status, nfeatures=500, thr=3.0, max_iters=2000,
                               conf=0.995, force_max_iters=False):
+        self._enter()
         h, w = frames.shape[1:3]
         cn = 1 if frames.dim() == 3 else frames.shape[3]
         self._check(self.lib.evh_pair_homography_batch(self.h, frames.data_ptr(), npairs, mode, w, h, cn, w * cn,
@@ -275,6 +289,7 @@ class Context:
     def stream_homography_batch(self, frames, out_H, out_status, state_in=None, state_out=None, nfeatures=500, thr=3.0,
                                 max_iters=2000, conf=0.995, force_max_iters=False):
         """frames: CUDA uint8 [n,h,w(,3)], n >= 2 consecutive frames of one stream -> n-1 pairs (stream semantics)."""
+        self._enter()
         n, h, w = frames.shape[:3]
         cn = 1 if frames.dim() == 3 else frames.shape[3]
         self._check(self.lib.evh_stream_homography_batch(
@@ -286,6 +301,7 @@ class Context:
                                       thr=3.0, max_iters=2000, conf=0.995, force_max_iters=False):
         """frames: CUDA uint8 [S,F,h,w(,3)] -- S independent streams of F consecutive frames each; out_H f64[S,F-1,9],
         out_status i32[S,F-1]; state_in / state_out f64[S,18] carry {H_sup, H_prev} of every stream between calls."""
+        self._enter()
         S, F, h, w = frames.shape[:4]
         cn = 1 if frames.dim() == 4 else frames.shape[4]
         self._check(self.lib.evh_multi_stream_homography_batch(

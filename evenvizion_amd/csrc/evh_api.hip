@@ -241,14 +241,17 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_desc, F * K * 32));
   A_(dalloc(c, &c->d_kp_count, F));
   A_(dalloc(c, &c->d_frame_flags, F));
-  A_(dalloc(c, &c->d_tmp_meta, F * K));
-  A_(dalloc(c, &c->d_tmp_resp, F * K));
+  A_(dalloc(c, &c->d_tmp_meta, F * EVH_NLEVELS * K));   // one frame-slot-sized segment per level
+  A_(dalloc(c, &c->d_tmp_resp, F * EVH_NLEVELS * K));
   A_(dalloc(c, &c->d_lvl_count, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_fast_thr, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_fast_hist, F * EVH_NLEVELS * 256));
   A_(dalloc(c, &c->d_fast_redo, F * EVH_NLEVELS + 1));
   A_(dalloc(c, &c->d_fast_hint, 16 + 8 * 256 + 8));
-  if (hipMemset(c->d_fast_hint, 0, sizeof(int) * (16 + 8 * 256 + 8)) != hipSuccess) return EVH_ERR_HIP;
+  if (hipMemset(c->d_fast_hint, 0, sizeof(int) * (16 + 8 * 256 + 8)) != hipSuccess) {
+    c->err = "hipMemset(d_fast_hint) failed";
+    return fail(EVH_ERR_HIP);
+  }
   A_(dalloc(c, &c->d_knn_idx, F * K * 2));
   A_(dalloc(c, &c->d_knn_d2, F * K * 2));
   A_(dalloc(c, &c->d_pts, F * K * 4));

@@ -850,13 +850,18 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
       }
     }
     __syncthreads();
-    int k1 = sh_i[1];
-    if (k1 > K1CAP) { overflow = true; k1 = K1CAP; }
-    // ---- Harris response of every stage-1 survivor
+    const int k1 = sh_i[1];
+    // retainBest keeps EVERY tie at the cut, so k1 has no bound but n (saturated / binary content ties massively on the
+    // integer score).  More survivors than the LDS list holds: spill path -- nothing is stored, the survivors are
+    // re-read from the candidate list and their Harris responses recomputed in each pass (same values, same cut).
+    const bool spill = k1 > K1CAP;                       // workgroup-uniform
     const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-    for (int j = tid; j < k1; j += 256) {
-      uint32_t c = keys[j];
-      resp[j] = harris_response(img, L.stride, (int)(c & 0xFFFu), (int)((c >> 12) & 0xFFFu));
+    // ---- Harris response of every stage-1 survivor
+    if (!spill) {
+      for (int j = tid; j < k1; j += 256) {
+        uint32_t c = keys[j];
+        resp[j] = harris_response(img, L.stride, (int)(c & 0xFFFu), (int)((c >> 12) & 0xFFFu));
+      }
     }
     __syncthreads();
     // ---- stage 2: value of the q-th largest response by a 4 x 8-bit radix select on order-preserving keys
@@ -868,10 +873,20 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
         const int shift = 24 - 8 * pass;
         hist[tid] = 0;
         __syncthreads();
-        for (int j = tid; j < k1; j += 256) {
-          uint32_t u = f32_order_key(resp[j]);
-          bool in = pass == 0 ? true : ((u >> (shift + 8)) == (prefix >> (shift + 8)));
-          if (in) atomicAdd(&hist[(u >> shift) & 0xFFu], 1u);
+        if (!spill) {
+          for (int j = tid; j < k1; j += 256) {
+            uint32_t u = f32_order_key(resp[j]);
+            bool in = pass == 0 ? true : ((u >> (shift + 8)) == (prefix >> (shift + 8)));
+            if (in) atomicAdd(&hist[(u >> shift) & 0xFFu], 1u);
+          }
+        } else {
+          for (int i = tid; i < n; i += 256) {
+            const uint32_t c = cand[i];
+            if ((c >> 24) < cut) continue;
+            uint32_t u = f32_order_key(harris_response(img, L.stride, (int)(c & 0xFFFu), (int)((c >> 12) & 0xFFFu)));
+            bool in = pass == 0 ? true : ((u >> (shift + 8)) == (prefix >> (shift + 8)));
+            if (in) atomicAdd(&hist[(u >> shift) & 0xFFu], 1u);
+          }
         }
         __syncthreads();
         int above;
@@ -882,21 +897,34 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
       uint32_t u = (prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix;
       cutf = __uint_as_float(u);
     }
-    for (int j = tid; j < k1; j += 256)
-      if (resp[j] >= cutf) {
-        int slot = atomicAdd(&sh_i[2], 1);
-        if (slot < K2CAP) { sel[slot] = keys[j]; selr[slot] = resp[j]; }
+    if (!spill) {
+      for (int j = tid; j < k1; j += 256)
+        if (resp[j] >= cutf) {
+          int slot = atomicAdd(&sh_i[2], 1);
+          if (slot < K2CAP) { sel[slot] = keys[j]; selr[slot] = resp[j]; }
+        }
+    } else {
+      for (int i = tid; i < n; i += 256) {
+        const uint32_t c = cand[i];
+        if ((c >> 24) < cut) continue;
+        const float r = harris_response(img, L.stride, (int)(c & 0xFFFu), (int)((c >> 12) & 0xFFFu));
+        if (r >= cutf) {
+          int slot = atomicAdd(&sh_i[2], 1);
+          if (slot < K2CAP) { sel[slot] = c; selr[slot] = r; }
+        }
       }
+    }
     __syncthreads();
     k2 = sh_i[2];
+    // the one hard bound left: a level cannot deliver more key points than a frame's slot holds (K2CAP == kcap);
+    // such a frame is flagged (EVH_PAIR_CAPACITY for its pairs), never truncated silently
     if (k2 > K2CAP) { overflow = true; k2 = K2CAP; }
-    if (k2 > L.kp_cap) { overflow = true; k2 = L.kp_cap; }
     // ---- canonical order inside the level: ascending (y, x) by rank counting
     for (int j = tid; j < k2; j += 256) {
       uint32_t kj = sel[j] & 0xFFFFFFu;
       int pos = 0;
       for (int i = 0; i < k2; i++) pos += ((sel[i] & 0xFFFFFFu) < kj) ? 1 : 0;
-      int64_t o = (int64_t)f * A.kcap + L.kp_base + pos;
+      int64_t o = ((int64_t)f * EVH_NLEVELS + l) * A.kcap + pos;
       A.tmp_meta[o] = ((uint32_t)l << 24) | kj;
       A.tmp_resp[o] = selr[j];
     }
@@ -907,15 +935,17 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
   }
 }
 
-// concatenates the per-level segments of one frame (canonical order = level, y, x) and derives kp.pt
+// concatenates the per-level segments of one frame (canonical order = level, y, x) and derives kp.pt; a frame whose
+// levels together hold more than kcap key points is flagged (its slot keeps the first kcap)
 __global__ __launch_bounds__(256) void k_pack(SelectArgs A) {
   const int f = blockIdx.x, tid = threadIdx.x;
   int base = 0;
   for (int l = 0; l < EVH_NLEVELS; l++) {
     const EvhLevel L = A.lv[l];
-    const int n = A.lvl_count[f * EVH_NLEVELS + l];
+    const int n = min(A.lvl_count[f * EVH_NLEVELS + l], A.kcap - base);
+    if (n < A.lvl_count[f * EVH_NLEVELS + l] && tid == 0) atomicOr(&A.frame_flags[f], 1);
     for (int j = tid; j < n; j += 256) {
-      const int64_t si = (int64_t)f * A.kcap + L.kp_base + j, o = (int64_t)f * A.kcap + base + j;
+      const int64_t si = ((int64_t)f * EVH_NLEVELS + l) * A.kcap + j, o = (int64_t)f * A.kcap + base + j;
       const uint32_t m = A.tmp_meta[si];
       A.kp_meta[o] = m;
       A.kp_resp[o] = A.tmp_resp[si];
@@ -1232,12 +1262,12 @@ int evh_launch_select(evh_ctx* c, int nframes) {
   A.frame_flags = c->d_frame_flags; A.kcap = c->kcap;
   A.tmp_meta = c->d_tmp_meta; A.tmp_resp = c->d_tmp_resp; A.lvl_count = c->d_lvl_count;
   EVH_HIP(c, hipMemsetAsync(c->d_frame_flags, 0, sizeof(int) * (size_t)nframes, c->stream));
-  // LDS capacities follow the largest per-level quota q0: stage 1 keeps 2*q0 + score ties, stage 2 q0 + response ties
-  // (overflow is flagged per frame -> EVH_PAIR_CAPACITY, never truncated silently); bounded by the fixed maxima
+  // LDS capacities: stage 1 keeps 2*q0 + score ties in LDS up to k1cap and spills beyond it (exact either way);
+  // stage 2 can hold a whole frame slot (kcap), the only hard bound left
   int q0 = 0;
   for (int l = 0; l < EVH_NLEVELS; l++) q0 = std::max(q0, A.lv[l].quota);
   A.k1cap = std::min(EVH_K1CAP, std::max(1024, (4 * q0 + 63) / 64 * 64));
-  A.k2cap = std::min(EVH_K2CAP, std::max(256, (q0 + q0 / 4 + 64 + 63) / 64 * 64));
+  A.k2cap = c->kcap;
   const size_t lds = sizeof(uint32_t) * 2 * ((size_t)A.k1cap + A.k2cap);
   hipLaunchKernelGGL(k_select, dim3(EVH_NLEVELS, nframes), dim3(256), lds, c->stream, A);
   EVH_HIP(c, hipGetLastError());

@@ -61,8 +61,8 @@ struct evh_ctx {
   uint8_t* d_desc = nullptr;      // [max_frames][kcap][32]
   int* d_kp_count = nullptr;      // [max_frames]
   int* d_frame_flags = nullptr;   // [max_frames] bit0: capacity overflow
-  uint32_t* d_tmp_meta = nullptr; // [max_frames][kcap] per-level segments before packing
-  float* d_tmp_resp = nullptr;    // [max_frames][kcap]
+  uint32_t* d_tmp_meta = nullptr; // [max_frames][8][kcap] per-level segments before packing
+  float* d_tmp_resp = nullptr;    // [max_frames][8][kcap]
   int* d_lvl_count = nullptr;     // [max_frames][8]
   int* d_fast_thr = nullptr;      // [max_frames][8] lifted FAST threshold
   unsigned* d_fast_hist = nullptr;// [max_frames][8][256] sampled score histogram

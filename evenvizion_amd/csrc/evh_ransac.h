@@ -24,6 +24,7 @@ struct EvhRansacArgs {
   double* H;             // final H per pair
   int* out_status;       // final status per pair
   int* found;            // single-problem entry
+  unsigned long long* prof;  // optional cycle accounting (debug, EVH_RANSAC_PROF); NULL normally
   int* info;             // [pair][8] (may be NULL): ransac iters, best inliers, LM iters for RANSAC #1 (+0) and #2 (+4)
 };
 

@@ -25,6 +25,9 @@
 #include "evh_ransac.h"
 #include <float.h>
 #include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -65,6 +68,13 @@ __device__ __forceinline__ unsigned rmax16(unsigned v) { return dmax<DPP_ROW_MIR
 __device__ __forceinline__ unsigned rmin16(unsigned v) { return dmin<DPP_ROW_MIRROR>(rmin8(v)); }
 __device__ __forceinline__ int rsum16(int v) {
   return dadd<DPP_ROW_MIRROR>(dadd<DPP_HALF_MIRROR>(dadd<DPP_XOR2>(dadd<DPP_XOR1>(v))));
+}
+// c ? a : b as one v_cndmask_b32 (the optimiser otherwise turns the candidate updates into exec-mask branches)
+__device__ __forceinline__ unsigned vsel(bool c, unsigned a, unsigned b) {
+  unsigned r;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
 }
 __device__ __forceinline__ unsigned hi32(double v) { return (unsigned)__double2hiint(v); }
 __device__ __forceinline__ unsigned lo32(double v) { return (unsigned)__double2loint(v); }
@@ -107,14 +117,17 @@ __device__ __forceinline__ double hyp(double a, double b) {
   return 0;
 }
 // the rotation scalars of one Jacobi step, plain form (reference order of operations)
-__device__ __noinline__ void rotation_scalars_slow(double p, double wk, double wl, double* c, double* s, double* t) {
+struct Cst { double c, s, t; };
+__device__ __noinline__ Cst rotation_scalars_slow(double p, double wk, double wl) {
   const double y = (wl - wk) * 0.5;
   double tt = fabs(y) + hyp(p, y);
   double sn = hyp(p, tt);
-  *c = tt / sn;
+  Cst r;
+  r.c = tt / sn;
   sn = p / sn; tt = (p / tt) * p;
   if (y < 0) sn = -sn, tt = -tt;
-  *s = sn; *t = tt;
+  r.s = sn; r.t = tt;
+  return r;
 }
 // the same values with the short sequences: |p| > DBL_EPSILON is given, so hyp(p, y) >= |p| > 0, t >= |p| and the
 // second hyp() always takes its "b >= a" branch; (p / t) * p == (|p| / t) * |p| because IEEE division and
@@ -124,8 +137,7 @@ __device__ __forceinline__ bool rotation_scalars(double p, double wk, double wl,
   const double ap = fabs(p), ay = fabs(y);
   const bool pg = ap > ay;
   const double hi = pg ? ap : ay;
-  double lo = pg ? ay : ap;
-  lo = lo < 1e-150 ? 0.0 : lo;                // such a quotient squared vanishes against 1 either way
+  const double lo = pg ? ay : ap;             // (a quotient too small for the short divide also vanishes against 1)
   const double q = div_by(lo, recip_refined(hi));
   const double h = hi * sqrt_1_2(1.0 + q * q);
   const double tt = ay + h;
@@ -142,10 +154,38 @@ __device__ __forceinline__ bool rotation_scalars(double p, double wk, double wl,
 
 struct RowMat {          // one eigen-problem: A full symmetric, V eigenvectors as rows, W eigenvalues, sort order
   double A[MS * MS];
-  double V[MS * MS];
+  double V[MS * MS];     // directly behind A: jacobi_one addresses both through one element index
   double W[MS];
   int ord[12];           // ord[p] = index of the p-th largest eigenvalue (selection-sort order of the reference)
 };
+static_assert(offsetof(RowMat, V) == sizeof(double) * MS * MS, "V must follow A");
+
+// Order of the eigenvalues (descending) into M.ord, rows of a wave in parallel; `active` is row-uniform.  Distinct
+// values: position = number of larger ones.  Equal values (degenerate input): replay the reference's selection sort
+// on the index list.
+template <int N>
+__device__ __forceinline__ void eig_order(RowMat& M, int lane, bool active) {
+  const int gl = lane & 15;
+  double* Wd = M.W;
+  int gt = 0, eq = 0;
+  if (active && gl < N) {
+    const double w = Wd[gl];
+#pragma unroll
+    for (int i = 0; i < N; i++) { const double wi = Wd[i]; gt += wi > w ? 1 : 0; eq += wi == w ? 1 : 0; }
+  }
+  const unsigned long long tie = __ballot(active && gl < N && eq != 1);   // != 1 also catches NaN
+  const bool row_tie = ((tie >> (lane & 48)) & 0xFFFFull) != 0ull;
+  if (active && gl < N && !row_tie) M.ord[gt] = gl;
+  if (active && row_tie && gl == 0) {
+    for (int i = 0; i < N; i++) M.ord[i] = i;
+    for (int a = 0; a < N - 1; a++) {
+      int mm = a;
+      for (int i = a + 1; i < N; i++) if (Wd[M.ord[mm]] < Wd[M.ord[i]]) mm = i;
+      const int tmp = M.ord[a]; M.ord[a] = M.ord[mm]; M.ord[mm] = tmp;
+    }
+  }
+  WSYNC();
+}
 
 // Symmetric eigen-solver (Jacobi with largest-pivot selection; eigenvalues sorted descending through M.ord), one
 // matrix per 16-lane row, up to four rows of a wavefront at once.  Arithmetic and pivot order are those of the
@@ -157,7 +197,7 @@ struct RowMat {          // one eigen-problem: A full symmetric, V eigenvectors 
 // The diagonal of A is dead after W is taken from it (lanes k and l park their unused products there).
 // Must be called by all 64 lanes; `active` is row-uniform.
 template <int N>
-__device__ __forceinline__ void jacobi_rows(RowMat& M, int lane, bool active) {
+__device__ __forceinline__ int jacobi_rows(RowMat& M, int lane, bool active) {
   const int gl = lane & 15, half = gl >> 3, m = gl & 7;
   const int idx = half ? m + 1 : m;
   const bool idx_ok = idx < N;
@@ -167,6 +207,7 @@ __device__ __forceinline__ void jacobi_rows(RowMat& M, int lane, bool active) {
   const int own_c = own_ok ? own : 1;
   const unsigned prio = half ? m : 8 + m;
   const int vc = gl < N ? gl : 0;
+  const int sgn = half ? 1 : -1, sidx = idx_ok ? sgn * idx : -64;
   double* A = M.A;
   double* V = M.V;
   double* Wd = M.W;
@@ -190,7 +231,8 @@ __device__ __forceinline__ void jacobi_rows(RowMat& M, int lane, bool active) {
   WSYNC();
   bool act = active;
   const int maxIters = N * N * 30;
-  for (int iters = 0; iters < maxIters; iters++) {
+  int iters = 0;
+  for (; iters < maxIters; iters++) {
     if (__ballot(act) == 0ull) break;
     // ---- pivot: first maximum of |candidate| over the row's 2N-2 owners, in the order R0.., C1..
     const bool cv = act && own_ok;
@@ -211,9 +253,8 @@ __device__ __forceinline__ void jacobi_rows(RowMat& M, int lane, bool active) {
     double c = 1, s = 0, t = 0;
     const bool fine = rotation_scalars(p, wk, wl, c, s, t);
     if (__ballot(act && !fine) != 0ull) {
-      double c2, s2, t2;
-      rotation_scalars_slow(p, wk, wl, &c2, &s2, &t2);
-      if (!fine) c = c2, s = s2, t = t2;
+      const Cst r = rotation_scalars_slow(p, wk, wl);
+      if (!fine) c = r.c, s = r.s, t = r.t;
     }
     double u = a0 * c - b0 * s, v = a0 * s + b0 * c;
     if (idx == l) u = 0;                        // A[k][l] = 0
@@ -229,42 +270,120 @@ __device__ __forceinline__ void jacobi_rows(RowMat& M, int lane, bool active) {
     const double fresh = A[own_c * MS + cidx];
     // ---- ... and the owners of k and l rescan: half 0 the column above, half 1 the row right of the diagonal,
     //      straight from the rotated values in registers (u = new A[idx][k], v = new A[idx][l])
-    const bool inu = idx_ok && (half ? idx > k : idx < k);
-    const bool inv = idx_ok && (half ? idx > l : idx < l);
+    const bool inu = sidx - sgn * k > 0;        // half 1: idx > k, half 0: idx < k (never for a lane without index)
+    const bool inv = sidx - sgn * l > 0;
     const unsigned uh = inu ? hi32(u) & 0x7FFFFFFFu : 0u, ul = inu ? lo32(u) : 0u;
     const unsigned vh = inv ? hi32(v) & 0x7FFFFFFFu : 0u, vl = inv ? lo32(v) : 0u;
     const unsigned muh = rmax8(uh), mvh = rmax8(vh);
     const unsigned mul_ = rmax8(uh == muh ? ul : 0u), mvl = rmax8(vh == mvh ? vl : 0u);
     const unsigned pu = rmin8(inu && uh == muh && ul == mul_ ? (unsigned)(idx << 1) | (hi32(u) >> 31) : 0xFFFFFFFFu);
     const unsigned pv = rmin8(inv && vh == mvh && vl == mvl ? (unsigned)(idx << 1) | (hi32(v) >> 31) : 0xFFFFFFFFu);
-    if (act) {
-      cval = fresh;
-      if (own == k) { cidx = (pu >> 1) & 15; cval = mk64(muh | (pu << 31), mul_); }
-      if (own == l) { cidx = (pv >> 1) & 15; cval = mk64(mvh | (pv << 31), mvl); }
+    {
+      const bool tk = act && own == k, tl = act && own == l;
+      cidx = (int)vsel(tk, (pu >> 1) & 15, vsel(tl, (pv >> 1) & 15, (unsigned)cidx));
+      const unsigned nh = vsel(tk, muh | (pu << 31), vsel(tl, mvh | (pv << 31), hi32(fresh)));
+      const unsigned nl = vsel(tk, mul_, vsel(tl, mvl, lo32(fresh)));
+      cval = mk64(nh, nl);
     }
   }
   WSYNC();
-  // ---- order of the eigenvalues (descending).  Distinct values: position = number of larger ones.  Equal values
-  //      (degenerate input): replay the reference's selection sort on the index list.
-  int gt = 0, eq = 0;
-  double w = 0;
-  if (active && gl < N) {
-    w = Wd[gl];
+  eig_order<N>(M, lane, active);
+  return iters;
+}
+
+// The same solver for ONE matrix served by the whole wavefront (refit, LM solves): the pivot (k, l, p) and the
+// eigenvalues it needs travel through SGPRs (v_readfirstlane / v_readlane), the rotations of A and V are one
+// instruction stream (rows 0-1 of the wave rotate A pairs, row 2 the V pairs), the rescans for k and for l run side
+// by side (row 0 / row 1) and row 1's results reach the candidate owners in row 0 by v_permlane16_swap.  W lives in
+// registers (lane j holds W[j]) and is stored to M.W at the end.  Same arithmetic, same pivot order, same result.
+template <int N>
+__device__ __forceinline__ int jacobi_one(RowMat& M, int lane) {
+  const int row = lane >> 4, gl = lane & 15, half = gl >> 3, m = gl & 7;
+  const int idx = half ? m + 1 : m;
+  const bool a_lane = row < 2 && idx < N;
+  const bool a_writer = row == 0 && idx < N;
+  const bool v_lane = row == 2 && gl < N;
+  const int own = half ? m : m + 1;
+  const bool own_ok = row == 0 && m <= N - 2;
+  const int own_c = m <= N - 2 ? own : 1;
+  const unsigned prio = half ? m : 8 + m;
+  const int sgn = half ? 1 : -1, sidx = a_lane ? sgn * idx : -64;
+  const int zidx = a_lane ? idx : 99;
+  // element index of this lane's pair inside M.A (V behind it): e0 = ebase + k * emult, e1 = ebase + l * emult
+  const int ebase = a_lane ? idx * MS : v_lane ? MS * MS + gl : 0;
+  const int emult = a_lane ? 1 : v_lane ? MS : 0;
+  double* D = M.A;
+  for (int e = lane; e < N * N; e += NL) { const int i = e / N, j = e - i * N; M.V[i * MS + j] = i == j ? 1.0 : 0.0; }
+  double wreg = lane < N ? D[lane * MS + lane] : 0.0;
+  int cidx = half ? own_c + 1 : 0;
+  double cval = 0;
+  if (own_ok) {
+    double mv = -1.0;
 #pragma unroll
-    for (int i = 0; i < N; i++) { const double wi = Wd[i]; gt += wi > w ? 1 : 0; eq += wi == w ? 1 : 0; }
-  }
-  const unsigned long long tie = __ballot(active && gl < N && eq != 1);   // != 1 also catches NaN
-  const bool row_tie = ((tie >> (lane & 48)) & 0xFFFFull) != 0ull;
-  if (active && gl < N && !row_tie) M.ord[gt] = gl;
-  if (active && row_tie && gl == 0) {
-    for (int i = 0; i < N; i++) M.ord[i] = i;
-    for (int a = 0; a < N - 1; a++) {
-      int mm = a;
-      for (int i = a + 1; i < N; i++) if (Wd[M.ord[mm]] < Wd[M.ord[i]]) mm = i;
-      const int tmp = M.ord[a]; M.ord[a] = M.ord[mm]; M.ord[mm] = tmp;
+    for (int j = 0; j < N; j++) {
+      const bool in = half ? j > own : j < own;
+      const double v = fabs(D[own * MS + j]);
+      if (in && mv < v) mv = v, cidx = j;
     }
+    cval = D[own * MS + cidx];
   }
   WSYNC();
+  const int maxIters = N * N * 30;
+  int iters = 0;
+  for (; iters < maxIters; iters++) {
+    // ---- pivot (row 0 holds the candidates; the other rows reduce zeros)
+    const unsigned ch = own_ok ? hi32(cval) & 0x7FFFFFFFu : 0u, cl = own_ok ? lo32(cval) : 0u;
+    const unsigned mh = rmax16(ch);
+    const unsigned ml = rmax16(ch == mh ? cl : 0u);
+    const bool win = own_ok && ch == mh && cl == ml;
+    const unsigned pack = (prio << 12) | ((hi32(cval) >> 31) << 8) | ((half ? own : cidx) << 4) | (half ? cidx : own);
+    const unsigned pk = rmin16(win ? pack : 0xFFFFFFFFu);
+    const unsigned spk = (unsigned)__builtin_amdgcn_readfirstlane((int)pk);
+    const double pabs = mk64((unsigned)__builtin_amdgcn_readfirstlane((int)mh), (unsigned)__builtin_amdgcn_readfirstlane((int)ml));
+    if (pabs <= DBL_EPSILON) break;
+    const int k = (spk >> 4) & 15, l = spk & 15;
+    const double p = (spk >> 8) & 1 ? -pabs : pabs;
+    const double wk = mk64((unsigned)__builtin_amdgcn_readlane((int)hi32(wreg), k), (unsigned)__builtin_amdgcn_readlane((int)lo32(wreg), k));
+    const double wl = mk64((unsigned)__builtin_amdgcn_readlane((int)hi32(wreg), l), (unsigned)__builtin_amdgcn_readlane((int)lo32(wreg), l));
+    const int e0 = ebase + k * emult, e1 = ebase + l * emult;
+    const double a0 = D[e0], b0 = D[e1];
+    double c = 1, s = 0, t = 0;
+    const bool fine = rotation_scalars(p, wk, wl, c, s, t);
+    if (!__builtin_amdgcn_readfirstlane((int)fine)) { const Cst r = rotation_scalars_slow(p, wk, wl); c = r.c; s = r.s; t = r.t; }
+    double x0 = a0 * c - b0 * s, x1 = a0 * s + b0 * c;
+    if (zidx == l) x0 = 0;                      // A[k][l] = 0
+    if (zidx == k) x1 = 0;
+    if (a_writer || v_lane) { D[e0] = x0; D[e1] = x1; }
+    if (a_writer) { D[k * MS + idx] = x0; D[l * MS + idx] = x1; }
+    {
+      const double wm = wreg - t, wp = wreg + t;
+      wreg = lane == k ? wm : lane == l ? wp : wreg;
+    }
+    WSYNC();
+    const double fresh = D[own_c * MS + cidx];
+    // ---- rescans: row 0 for k on the first components, row 1 for l on the second ones
+    const double xs = row == 1 ? x1 : x0;
+    const int Ks = row == 1 ? l : k;
+    const bool inr = sidx - sgn * Ks > 0;
+    const unsigned xh = inr ? hi32(xs) & 0x7FFFFFFFu : 0u, xl = inr ? lo32(xs) : 0u;
+    const unsigned m8h = rmax8(xh);
+    const unsigned m8l = rmax8(xh == m8h ? xl : 0u);
+    const unsigned pw = rmin8(inr && xh == m8h && xl == m8l ? (unsigned)(idx << 1) | (hi32(xs) >> 31) : 0xFFFFFFFFu);
+    const unsigned o_pw = __builtin_amdgcn_permlane16_swap(pw, pw, false, false)[1];     // row 0 <- row 1
+    const unsigned o_h = __builtin_amdgcn_permlane16_swap(m8h, m8h, false, false)[1];
+    const unsigned o_l = __builtin_amdgcn_permlane16_swap(m8l, m8l, false, false)[1];
+    {
+      const bool tk = own == k, tl = own == l;
+      cidx = (int)vsel(tk, (pw >> 1) & 15, vsel(tl, (o_pw >> 1) & 15, (unsigned)cidx));
+      const unsigned nh = vsel(tk, m8h | (pw << 31), vsel(tl, o_h | (o_pw << 31), hi32(fresh)));
+      const unsigned nl = vsel(tk, m8l, vsel(tl, o_l, lo32(fresh)));
+      cval = mk64(nh, nl);
+    }
+  }
+  if (lane < N) M.W[lane] = wreg;
+  WSYNC();
+  eig_order<N>(M, lane, lane < GL);
+  return iters;
 }
 
 // de-normalise the smallest-eigenvalue eigenvector into H (runKernel's tail)
@@ -424,6 +543,14 @@ __device__ __forceinline__ int wave_sum(int v) {
   return v;
 }
 
+// optional in-kernel cycle accounting (EVH_RANSAC_PROF=1): slots of A.prof, accumulated by thread 0
+enum { PF_CALLS = 0, PF_HYP, PF_CHUNKS, PF_COMPACT, PF_REFIT, PF_LM, PF_LM_ITERS, PF_SOLVE8, PF_EVAL, PF_TOTAL, PF_ROT9,
+       PF_ROT8, PF_SETUP, PF_NSLOTS };
+__device__ __forceinline__ unsigned long long pf_now() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ void pf_add(unsigned long long* prof, int slot, unsigned long long v) {
+  if (prof && threadIdx.x == 0) atomicAdd(prof + slot, v);
+}
+
 struct SolveLds {        // scratch of the single-problem stages (refit, LM): used by wave 0 only
   double bestH[9];
   double H[9];           // result of the last single-problem DLT / LM
@@ -434,7 +561,8 @@ struct SolveLds {        // scratch of the single-problem stages (refit, LM): us
 };
 
 // ---- single-problem normalised DLT on `count` rows (ax,ay,bx,by): sums in row order, one lane per sum; wave 0 ------
-__device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */) {
+__device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */,
+                                         unsigned long long* prof = nullptr) {
   double* T = S.T;
   // centroids: lanes 0..3 own cm.x, cm.y, cM.x, cM.y  (m = b columns, M = a columns)
   double acc = 0;
@@ -504,7 +632,7 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
   }
   if (lane < 45) { M.A[ej * MS + ek] = s; M.A[ek * MS + ej] = s; }
   WSYNC();
-  jacobi_rows<9>(M, lane, lane < GL);
+  pf_add(prof, PF_ROT9, jacobi_one<9>(M, lane));
   if (lane == 0) {
     double H[9];
     dlt_finish(M, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
@@ -518,13 +646,14 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
 // all 64 lanes of wave 0; Ain / b / x live in LDS.  Back-substitution keeps the serial summation orders: lane i forms
 // s_i = (sum_j u_i[j] b[j]) / w_i, lane j accumulates x[j] += s_i u_i[j] over i ascending.
 __device__ __forceinline__ void eig_solve8_wave(RowMat& M, int lane, const double* Ain /*LDS 64*/, const double* b /*LDS 8 or null*/,
-                                double* x /*LDS 8 or 64*/) {
+                                double* x /*LDS 8 or 64*/, unsigned long long* prof = nullptr) {
+  const unsigned long long pt0 = pf_now();
   {
     const int i = lane >> 3, j = lane & 7;
     M.A[i * MS + j] = Ain[min(i, j) * 8 + max(i, j)];
   }
   WSYNC();
-  jacobi_rows<8>(M, lane, lane < GL);
+  pf_add(prof, PF_ROT8, jacobi_one<8>(M, lane));
   double threshold = 0;
   for (int i = 0; i < 8; i++) threshold += M.W[M.ord[i]];
   threshold *= DBL_EPSILON * 2;
@@ -564,6 +693,7 @@ __device__ __forceinline__ void eig_solve8_wave(RowMat& M, int lane, const doubl
     x[r * 8 + j] = acc;
   }
   WSYNC();
+  pf_add(prof, PF_SOLVE8, pf_now() - pt0);
 }
 
 // One pass of the refinement callback over the rows at parameters h[0..7] (LDS): S.sc[slotS] = sum of squared
@@ -656,12 +786,15 @@ __device__ __forceinline__ double dot8(const double* a, const double* b) {
 
 // Levenberg-Marquardt refinement of S.H[0..7] over `count` rows (<= 10 iterations). Returns iterations.  Wave 0.
 // S.sc: 0 = S, 1 = rmax of the kept point, 2 = lambda, 3 = lc, 4 = nu, 5 = Sd, 6 = rmax of the trial point
-__device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const float* rows, int count) {
+__device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const float* rows, int count,
+                                         unsigned long long* prof = nullptr) {
   const int maxIters = 10;
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   if (lane < 8) S.x[lane] = S.H[lane];
   WSYNC();
+  unsigned long long pe = pf_now();
   lm_eval(S, lane, rows, count, S.x, true, 0, 1);
+  pf_add(prof, PF_EVAL, pf_now() - pe);
   if (lane < 8) S.D[lane] = S.A8[lane * 8 + lane];
   if (lane == 0) { S.sc[2] = 1; S.sc[3] = 0.75; }  // lambda, lc
   WSYNC();
@@ -672,10 +805,12 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
       S.Ap[lane] = i == j ? S.A8[lane] + S.sc[2] * S.D[i] : S.A8[lane];
     }
     WSYNC();
-    eig_solve8_wave(M, lane, S.Ap, S.v, S.d);
+    eig_solve8_wave(M, lane, S.Ap, S.v, S.d, prof);
     if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
     WSYNC();
+    pe = pf_now();
     lm_eval(S, lane, rows, count, S.xd, false, 5, 6);
+    pf_add(prof, PF_EVAL, pf_now() - pe);
     // trial residual -> Sd, gain ratio R; lane 0 decides, the (rare) inverse is done by the whole wave
     if (lane == 0) {
       const double Rlo = 0.25, Rhi = 0.75;
@@ -708,7 +843,7 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
     }
     WSYNC();
     if (S.ib[1]) {
-      eig_solve8_wave(M, lane, S.A8, nullptr, S.Inv);
+      eig_solve8_wave(M, lane, S.A8, nullptr, S.Inv, prof);
       if (lane == 0) {
         double maxval = DBL_EPSILON;
         for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(S.Inv[i * 8 + i]));
@@ -723,7 +858,9 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
     if (accepted) {
       if (lane < 8) { const double t = S.x[lane]; S.x[lane] = S.xd[lane]; S.xd[lane] = t; }
       WSYNC();
+      pe = pf_now();
       lm_eval(S, lane, rows, count, S.x, true, 0, 1);   // residuals / Jacobian at the accepted point (S = Sd again)
+      pf_add(prof, PF_EVAL, pf_now() - pe);
     }
     iter++;
     // norm(r, INF) of the kept residual, norm(d, INF)
@@ -756,7 +893,8 @@ struct BlockLds {
 // compacted inliers.  Ends with a workgroup barrier.
 template <int NW>
 __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const float* rows, int n, double thr, int maxItersArg, double conf,
-                                      int force_max, uint8_t* mask, float* crow, int* info) {
+                                      int force_max, uint8_t* mask, float* crow, int* info, unsigned long long* prof) {
+  const unsigned long long pf0 = pf_now();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15;
   SolveLds& S = B.s;
   if (info && tid < 3) info[tid] = 0;
@@ -807,7 +945,9 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
     }
     const bool valid = check_subset4(Mx, My, mx, my_);
     double H[9];
+    const unsigned long long ps0 = pf_now();
     const bool ok = dlt4_rows(M, lane, valid, Mx, My, mx, my_, H);
+    pf_add(prof, PF_SETUP, pf_now() - ps0);
     int good = 0;
     if (ok) {   // the 16 lanes of the row split the points; integer count, order-free
       float Hf[8];
@@ -850,6 +990,8 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
   }
   __threadfence_block();
   __syncthreads();
+  const unsigned long long pf1 = pf_now();
+  pf_add(prof, PF_CALLS, 1); pf_add(prof, PF_HYP, pf1 - pf0); pf_add(prof, PF_CHUNKS, chunk);
   if (info && tid == 0) { info[0] = iter; info[1] = maxGood; }
   if (maxGood <= 0) return false;
   if (wave == 0) {
@@ -875,14 +1017,20 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
     WSYNC();
     if (lane < 9) S.H[lane] = S.bestH[lane];
     WSYNC();
+    const unsigned long long pf2 = pf_now();
+    pf_add(prof, PF_COMPACT, pf2 - pf1);
     if (ni > 0) {
-      dlt_rows(S, B.m[0][0], lane, crow, ni, S.H);  // keeps the RANSAC model when the refit is degenerate
-      const int it = lm_refine(S, B.m[0][0], lane, crow, ni);
+      dlt_rows(S, B.m[0][0], lane, crow, ni, S.H, prof);  // keeps the RANSAC model when the refit is degenerate
+      const unsigned long long pf3 = pf_now();
+      pf_add(prof, PF_REFIT, pf3 - pf2);
+      const int it = lm_refine(S, B.m[0][0], lane, crow, ni, prof);
+      pf_add(prof, PF_LM, pf_now() - pf3); pf_add(prof, PF_LM_ITERS, it);
       if (info && lane == 0) info[2] = it;
     }
   }
   __threadfence_block();
   __syncthreads();
+  pf_add(prof, PF_TOTAL, pf_now() - pf0);
   return true;
 }
 
@@ -986,7 +1134,7 @@ __device__ __forceinline__ int compute_homography_block(BlockLds<NW>& B, const f
     __syncthreads();
     use = trow;
   }
-  const bool found = find_homography_block<NW>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info);
+  const bool found = find_homography_block<NW>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
   if (wave == 0) {
     int s = 0;
     for (int i = lane; i < n; i += NL) s += mask[i];
@@ -1011,7 +1159,7 @@ __global__ __launch_bounds__(NW * NL) void k_find_homography(EvhRansacArgs A) {
   BlockLds<NW>& B = block_lds<NW>();
   const int tid = threadIdx.x;
   const int n = A.n_fixed;
-  const bool found = find_homography_block<NW>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info);
+  const bool found = find_homography_block<NW>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info, A.prof);
   if (tid < 9) A.H[tid] = found ? B.s.H[tid] : 0.0;
   if (tid == 0) A.found[0] = found ? 1 : 0;
 }
@@ -1041,7 +1189,7 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_static(EvhRansacArgs A) {
   float* crow = A.crow + (int64_t)p * A.row_stride * 4;
   int* rbin = reinterpret_cast<int*>(A.lm + (int64_t)p * A.row_stride * 4);
   int* info = A.info ? A.info + 8 * p : nullptr;
-  const bool found = find_homography_block<NW>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info);
+  const bool found = find_homography_block<NW>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
   if (!found) {
     if (tid == 0) { A.status[p] = EVH_PAIR_NO_PROVISIONAL_H; A.npts2[p] = 0; }
     return;
@@ -1159,11 +1307,31 @@ int evh_launch_ransac_static(evh_ctx* c, const EvhRansacArgs& A, int npairs) {
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
-int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A, int npairs, int nstreams, int pitch) {
+int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A_, int npairs, int nstreams, int pitch) {
   if (npairs <= 0) return EVH_SUCCESS;
+  EvhRansacArgs A = A_;
+  static const bool want_prof = getenv("EVH_RANSAC_PROF") != nullptr;   // debugging aid: cycle accounting to stderr
+  unsigned long long* d_prof = nullptr;
+  if (want_prof) {
+    EVH_HIP(c, hipMalloc(&d_prof, sizeof(unsigned long long) * PF_NSLOTS));
+    EVH_HIP(c, hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * PF_NSLOTS, c->stream));
+    A.prof = d_prof;
+  }
   // nstreams == 0: independent pairs; otherwise nstreams sequential scans of npairs pairs each, `pitch` pair slots apart
   if (nstreams > 0) EVH_LAUNCH_NW(waves_for(nstreams, A.force_max), k_ransac_final_stream, nstreams, c->stream, A, npairs, pitch);
   else EVH_LAUNCH_NW(waves_for(npairs, A.force_max), k_ransac_final_pairs, npairs, c->stream, A);
   EVH_HIP(c, hipGetLastError());
+  if (d_prof) {
+    unsigned long long h[PF_NSLOTS];
+    EVH_HIP(c, hipStreamSynchronize(c->stream));
+    EVH_HIP(c, hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+    (void)hipFree(d_prof);
+    const double n = h[PF_CALLS] ? (double)h[PF_CALLS] : 1.0;
+    fprintf(stderr, "[evh ransac_final prof] calls %llu | per call (cycles): total %.0f hyp %.0f (chunks %.2f, dlt4+jacobi %.0f) "
+            "compact %.0f refit %.0f lm %.0f (iters %.2f, solve8 %.0f, eval %.0f) | rotations: 9x9 %.1f 8x8 %.1f\n",
+            h[PF_CALLS], h[PF_TOTAL] / n, h[PF_HYP] / n, h[PF_CHUNKS] / n, h[PF_SETUP] / n, h[PF_COMPACT] / n,
+            h[PF_REFIT] / n, h[PF_LM] / n, h[PF_LM_ITERS] / n, h[PF_SOLVE8] / n, h[PF_EVAL] / n, h[PF_ROT9] / n,
+            h[PF_ROT8] / n);
+  }
   return EVH_SUCCESS;
 }

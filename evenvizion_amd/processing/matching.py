@@ -49,9 +49,14 @@ class KeyPoints:
         idx = torch.empty(nq, 2, dtype=torch.int32, device=dev)
         d2 = torch.empty(nq, 2, dtype=torch.int32, device=dev)
         pts = torch.empty(nq, 4, dtype=torch.float32, device=dev)
-        ctx.knn2(runtime.to_device(q), runtime.to_device(t), idx, d2)
-        n, st = ctx.ratio_unique_filter(idx, d2, runtime.to_device(xy_q), runtime.to_device(xy_t), pts, ratio=ratio,
-                                        min_matches=min_matching_pts)
+        # all four uploads live in named locals until ratio_unique_filter (which synchronises the context's stream)
+        # has returned: a temporary freed right after an asynchronous launch could be handed to the next upload by
+        # torch's caching allocator while the kernel is still reading it
+        d_q, d_t, d_xy_q, d_xy_t = (runtime.to_device(a) for a in (q, t, xy_q, xy_t))
+        ctx.knn2(d_q, d_t, idx, d2)
+        n, st = ctx.ratio_unique_filter(idx, d2, d_xy_q, d_xy_t, pts, ratio=ratio, min_matches=min_matching_pts)
+        ctx.order_torch_after()
+        del d_q, d_t, d_xy_q, d_xy_t
         if st == PAIR_FEW_MATCHES:
             raise NoMatchesException("len(matches) < min_matching_pts {}".format(min_matching_pts), "couldn't process")
         return ctx, pts[:n]

@@ -14,7 +14,7 @@ import logging
 import numpy as np
 
 from .. import runtime
-from .._lib import PAIR_OK
+from .._lib import PAIR_OK, PAIR_CAPACITY, EvhError
 
 CHUNK_FRAMES = 64   # frames uploaded per GPU call (pairs per call = CHUNK_FRAMES - 1)
 
@@ -43,7 +43,9 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     if dw > w0 or dh > h0:
         raise NotImplementedError("resize_width larger than the frame (INTER_AREA enlargement) is outside the hot path")
     chunk_frames = max(2, int(chunk_frames))
-    ctx = runtime.get_context(max(w0, dw), max(h0, dh), chunk_frames, nfeatures)
+    # sized for the RESIZED frames: only those go through ORB (evh_resize_area_u8 does not depend on the context's
+    # geometry), so a 4K source with resize_width=400 allocates 400-wide buffers
+    ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures)
     dev = runtime.device()
     shape_small = (chunk_frames, dh, dw) if cn == 1 else (chunk_frames, dh, dw, cn)
     small = torch.empty(shape_small, dtype=torch.uint8, device=dev)
@@ -75,6 +77,11 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
         sts = st_dev[:n - 1].cpu().numpy()
         for k in range(n - 1):
             frame_no += 1
+            if sts[k] == PAIR_CAPACITY:
+                # not a "no homography" outcome of the reference: a frame delivered more tied key points than a frame
+                # slot holds (see include/evhip.h, EVH_PAIR_CAPACITY) -- repeating H_prev would hide a wrong result
+                raise EvhError("frame %d or %d holds more key points (ties at the retainBest cut) than a frame slot "
+                               "of this context; raise nfeatures capacity" % (frame_no - 1, frame_no))
             if sts[k] != PAIR_OK:
                 logging.info("pair ending at frame %d: no homography (status %d)", frame_no, int(sts[k]))
                 if not none_H_processing or not np.all(np.isfinite(Hs[k])):

@@ -111,6 +111,9 @@ def test_fast_threshold_lifting_is_exact(ctx):
     frames.append(tex)
     rng = np.random.default_rng(8)
     frames.append(rng.integers(0, 256, (720, 1280), dtype=np.uint8))   # white noise: the pre-test passes almost everywhere
+    # binary noise: the integer FAST score ties massively at the retainBest cut (all ties are kept, so stage 1 of the
+    # selection holds far more survivors than its LDS list: the spill path of k_select)
+    frames.append((rng.integers(0, 2, (720, 1280)) * 255).astype(np.uint8))
     frames = np.stack(frames)
     res = {}
     for lift in (True, False):
@@ -126,6 +129,74 @@ def test_fast_threshold_lifting_is_exact(ctx):
             for k in ("octave", "lx", "ly"):
                 assert np.array_equal(g[k], o[k]), (lift, f, k)
             assert np.array_equal(g["desc"], o["desc"]) and np.array_equal(g["xy"], o["xy"])
+
+
+def _dots(h, w, step, shift=(0, 0)):
+    """isolated bright pixels on a lattice: every one is a FAST corner with the same score AND the same Harris
+    response, i.e. one big tie at both retainBest cuts"""
+    img = np.full((h, w), 40, np.uint8)
+    for y in range(40 + shift[1], h - 40, step):
+        for x in range(40 + shift[0], w - 40, step):
+            img[y, x] = 230
+    return img
+
+
+def test_tied_key_points_are_all_kept(ctx):
+    """retainBest keeps EVERY tie at the cut (frame_processing.py:59-61 -> KeyPointsFilter::retainBest): a lattice of
+    identical corners gives far more key points than nfeatures on level 0 (324 where the quota is 104), saturated /
+    binary content ties on the FAST score.  Key-point sets, descriptors and the pair result equal the oracle's."""
+    prev, cur, _ = S.make_pair(31, 400, 224)
+    binary = [((a > 128) * 255).astype(np.uint8) for a in (prev, cur)]          # saturated 0 / 255 blocks
+    frames = np.stack([_dots(224, 400, 12), _dots(224, 400, 12, (3, 2)), _dots(224, 400, 16), _dots(224, 400, 16, (2, 1)),
+                       binary[0], binary[1]])
+    ctx.orb_detect_batch(dev(frames))
+    counts = []
+    for f in range(len(frames)):
+        g, o = ctx.orb_download(f), O.orb_detect(frames[f])
+        counts.append(len(o["xy"]))
+        for k in ("octave", "lx", "ly"):
+            assert np.array_equal(g[k], o[k]), (f, k)
+        assert np.array_equal(g["desc"], o["desc"]) and np.array_equal(g["xy"], o["xy"])
+        assert np.array_equal(g["response"].view(np.uint32), o["response"].view(np.uint32))
+    assert counts[0] > 600 and counts[0] <= ctx.lib.evh_orb_capacity(ctx.h)      # 609 key points for nfeatures = 500
+    n = 3
+    H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+    st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    ctx.pair_homography_batch(dev(frames), n, 0, H, st)
+    ctx.synchronize()
+    Ho, so = O.pairs_gray_batch(frames)
+    assert np.array_equal(st.cpu().numpy(), so)
+    Hg = H.cpu().numpy().reshape(-1, 3, 3)
+    for p in range(n):
+        if so[p] == 0:
+            assert np.allclose(Hg[p], Ho[p], rtol=1e-9, atol=1e-12)
+
+
+def test_frame_capacity_is_a_pair_status(ctx):
+    """The one hard bound: a frame slot holds evh_orb_capacity() key points.  A frame whose tie set is larger (here
+    1000 identical corners for nfeatures = 500; the oracle counts them) gives EVH_PAIR_CAPACITY for ITS pairs only --
+    the other pairs of the batch are computed, the call succeeds -- and the Python stream driver raises instead of
+    repeating the previous H."""
+    from evenvizion_amd._lib import EvhError, PAIR_CAPACITY
+    from evenvizion_amd.processing import get_homography_dict
+    cap = ctx.lib.evh_orb_capacity(ctx.h)
+    prev, cur, _ = S.make_pair(33, 400, 224)
+    crowded = _dots(224, 400, 8)
+    assert len(O.orb_detect(crowded)["xy"]) > cap
+    frames = np.stack([prev, cur, crowded, _dots(224, 400, 8, (2, 1)), prev, cur])
+    H = torch.zeros(3, 9, dtype=torch.float64, device="cuda")
+    st = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+    ctx.pair_homography_batch(dev(frames), 3, 0, H, st)
+    ctx.synchronize()
+    Ho, so = O.pairs_gray_batch(frames[:2])
+    assert st.cpu().tolist() == [int(so[0]), PAIR_CAPACITY, int(so[0])]
+    Hg = H.cpu().numpy().reshape(-1, 3, 3)
+    assert np.allclose(Hg[0], Ho[0], rtol=1e-9, atol=1e-12) and np.array_equal(Hg[0], Hg[2])
+    with pytest.raises(EvhError):
+        ctx.orb_download(2)
+    assert len(ctx.orb_download(1)["xy"]) == len(O.orb_detect(cur)["xy"])
+    with pytest.raises(EvhError):
+        get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in (prev, cur, crowded, cur)]), resize_width=400)
 
 
 def test_flat_frame_has_no_keypoints(ctx):
