@@ -26,6 +26,7 @@
 #include <float.h>
 #include <math.h>
 #include <stddef.h>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -118,7 +119,7 @@ __device__ __forceinline__ double hyp(double a, double b) {
 }
 // the rotation scalars of one Jacobi step, plain form (reference order of operations)
 struct Cst { double c, s, t; };
-__device__ __noinline__ Cst rotation_scalars_slow(double p, double wk, double wl) {
+__device__ __forceinline__ Cst rotation_scalars_plain(double p, double wk, double wl) {
   const double y = (wl - wk) * 0.5;
   double tt = fabs(y) + hyp(p, y);
   double sn = hyp(p, tt);
@@ -131,8 +132,9 @@ __device__ __noinline__ Cst rotation_scalars_slow(double p, double wk, double wl
 }
 // the same values with the short sequences: |p| > DBL_EPSILON is given, so hyp(p, y) >= |p| > 0, t >= |p| and the
 // second hyp() always takes its "b >= a" branch; (p / t) * p == (|p| / t) * |p| because IEEE division and
-// multiplication are sign-symmetric.  `ok` is false when an operand is too large for the unscaled sequences.
-__device__ __forceinline__ bool rotation_scalars(double p, double wk, double wl, double& c, double& s, double& t) {
+// multiplication are sign-symmetric.  The caller has checked that no operand can be too large for the unscaled
+// sequences (small ones are harmless: a quotient that loses its last bits is one whose square vanishes against 1).
+__device__ __forceinline__ void rotation_scalars(double p, double wk, double wl, double& c, double& s, double& t) {
   const double y = (wl - wk) * 0.5;
   const double ap = fabs(p), ay = fabs(y);
   const bool pg = ap > ay;
@@ -149,7 +151,6 @@ __device__ __forceinline__ bool rotation_scalars(double p, double wk, double wl,
   double t2 = q2 * ap;
   if (y < 0) ss = -ss, t2 = -t2;
   s = ss; t = t2;
-  return sn < 0x1p400;                        // also false for NaN
 }
 
 struct RowMat {          // one eigen-problem: A full symmetric, V eigenvectors as rows, W eigenvalues, sort order
@@ -211,10 +212,19 @@ __device__ __forceinline__ int jacobi_rows(RowMat& M, int lane, bool active) {
   double* A = M.A;
   double* V = M.V;
   double* Wd = M.W;
-  if (active) {
-    for (int e = gl; e < N * N; e += GL) { const int i = e / N, j = e - i * N; V[i * MS + j] = i == j ? 1.0 : 0.0; }
+  unsigned amax = 0;                            // largest high word of |a_ij|: decides once whether the short divide /
+  if (active) {                                 // square-root sequences are safe for the whole solve (see below)
+    for (int e = gl; e < N * N; e += GL) {
+      const int i = e / N, j = e - i * N;
+      V[i * MS + j] = i == j ? 1.0 : 0.0;
+      amax = max(amax, hi32(A[i * MS + j]) & 0x7FFFFFFFu);
+    }
     if (gl < N) Wd[gl] = A[gl * MS + gl];
   }
+  // Rotations preserve the Frobenius norm, so with every |a_ij| < 2^300 all later entries, eigenvalue estimates and
+  // the hypotenuses built from them stay below 2^310: no operand of the unscaled sequences can leave their range.
+  // Anything larger (or NaN) sends the whole wave through the plain `/` and sqrt() forms.
+  const bool plain = __ballot(active && rmax16(amax) >= 0x52B00000u) != 0ull;
   // initial indR[own] / indC[own]: first maximum of the row right of / the column above the diagonal
   int cidx = half ? own_c + 1 : 0;
   double cval = 0;
@@ -232,6 +242,8 @@ __device__ __forceinline__ int jacobi_rows(RowMat& M, int lane, bool active) {
   bool act = active;
   const int maxIters = N * N * 30;
   int iters = 0;
+  auto sweep = [&](auto plain_tag) {
+  constexpr bool PLAIN = decltype(plain_tag)::value;
   for (; iters < maxIters; iters++) {
     if (__ballot(act) == 0ull) break;
     // ---- pivot: first maximum of |candidate| over the row's 2N-2 owners, in the order R0.., C1..
@@ -251,11 +263,8 @@ __device__ __forceinline__ int jacobi_rows(RowMat& M, int lane, bool active) {
     const double a0 = A[idx_c * MS + k], b0 = A[idx_c * MS + l];
     const double va = V[k * MS + vc], vb = V[l * MS + vc];
     double c = 1, s = 0, t = 0;
-    const bool fine = rotation_scalars(p, wk, wl, c, s, t);
-    if (__ballot(act && !fine) != 0ull) {
-      const Cst r = rotation_scalars_slow(p, wk, wl);
-      if (!fine) c = r.c, s = r.s, t = r.t;
-    }
+    if (PLAIN) { const Cst r = rotation_scalars_plain(p, wk, wl); c = r.c; s = r.s; t = r.t; }
+    else rotation_scalars(p, wk, wl, c, s, t);
     double u = a0 * c - b0 * s, v = a0 * s + b0 * c;
     if (idx == l) u = 0;                        // A[k][l] = 0
     if (idx == k) v = 0;
@@ -286,6 +295,8 @@ __device__ __forceinline__ int jacobi_rows(RowMat& M, int lane, bool active) {
       cval = mk64(nh, nl);
     }
   }
+  };
+  if (plain) sweep(std::true_type{}); else sweep(std::false_type{});
   WSYNC();
   eig_order<N>(M, lane, active);
   return iters;
@@ -313,7 +324,13 @@ __device__ __forceinline__ int jacobi_one(RowMat& M, int lane) {
   const int ebase = a_lane ? idx * MS : v_lane ? MS * MS + gl : 0;
   const int emult = a_lane ? 1 : v_lane ? MS : 0;
   double* D = M.A;
-  for (int e = lane; e < N * N; e += NL) { const int i = e / N, j = e - i * N; M.V[i * MS + j] = i == j ? 1.0 : 0.0; }
+  unsigned amax = 0;
+  for (int e = lane; e < N * N; e += NL) {
+    const int i = e / N, j = e - i * N;
+    M.V[i * MS + j] = i == j ? 1.0 : 0.0;
+    amax = max(amax, hi32(D[i * MS + j]) & 0x7FFFFFFFu);
+  }
+  const bool plain = __ballot(amax >= 0x52B00000u) != 0ull;     // see jacobi_rows
   double wreg = lane < N ? D[lane * MS + lane] : 0.0;
   int cidx = half ? own_c + 1 : 0;
   double cval = 0;
@@ -330,6 +347,8 @@ __device__ __forceinline__ int jacobi_one(RowMat& M, int lane) {
   WSYNC();
   const int maxIters = N * N * 30;
   int iters = 0;
+  auto sweep = [&](auto plain_tag) {
+  constexpr bool PLAIN = decltype(plain_tag)::value;
   for (; iters < maxIters; iters++) {
     // ---- pivot (row 0 holds the candidates; the other rows reduce zeros)
     const unsigned ch = own_ok ? hi32(cval) & 0x7FFFFFFFu : 0u, cl = own_ok ? lo32(cval) : 0u;
@@ -348,8 +367,8 @@ __device__ __forceinline__ int jacobi_one(RowMat& M, int lane) {
     const int e0 = ebase + k * emult, e1 = ebase + l * emult;
     const double a0 = D[e0], b0 = D[e1];
     double c = 1, s = 0, t = 0;
-    const bool fine = rotation_scalars(p, wk, wl, c, s, t);
-    if (!__builtin_amdgcn_readfirstlane((int)fine)) { const Cst r = rotation_scalars_slow(p, wk, wl); c = r.c; s = r.s; t = r.t; }
+    if (PLAIN) { const Cst r = rotation_scalars_plain(p, wk, wl); c = r.c; s = r.s; t = r.t; }
+    else rotation_scalars(p, wk, wl, c, s, t);
     double x0 = a0 * c - b0 * s, x1 = a0 * s + b0 * c;
     if (zidx == l) x0 = 0;                      // A[k][l] = 0
     if (zidx == k) x1 = 0;
@@ -380,6 +399,8 @@ __device__ __forceinline__ int jacobi_one(RowMat& M, int lane) {
       cval = mk64(nh, nl);
     }
   }
+  };
+  if (plain) sweep(std::true_type{}); else sweep(std::false_type{});
   if (lane < N) M.W[lane] = wreg;
   WSYNC();
   eig_order<N>(M, lane, lane < GL);
@@ -545,7 +566,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // optional in-kernel cycle accounting (EVH_RANSAC_PROF=1): slots of A.prof, accumulated by thread 0
 enum { PF_CALLS = 0, PF_HYP, PF_CHUNKS, PF_COMPACT, PF_REFIT, PF_LM, PF_LM_ITERS, PF_SOLVE8, PF_EVAL, PF_TOTAL, PF_ROT9,
-       PF_ROT8, PF_SETUP, PF_NSLOTS };
+       PF_ROT8, PF_SETUP, PF_RNG, PF_COUNT, PF_BARRIER, PF_REPLAY, PF_NSLOTS };
 __device__ __forceinline__ unsigned long long pf_now() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ void pf_add(unsigned long long* prof, int slot, unsigned long long v) {
   if (prof && threadIdx.x == 0) atomicAdd(prof + slot, v);
@@ -922,6 +943,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
   bool stop = false;
   while (!stop && iter < niters) {
     // every lane advances the generator identically through HC quadruples; the lanes of hypothesis h keep quadruple #h
+    const unsigned long long pr0 = pf_now();
     int my[4] = {0, 1, 2, 3};
     for (int h = 0; h < HC; h++) {
       int q[4];
@@ -946,8 +968,10 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
     const bool valid = check_subset4(Mx, My, mx, my_);
     double H[9];
     const unsigned long long ps0 = pf_now();
+    pf_add(prof, PF_RNG, ps0 - pr0);
     const bool ok = dlt4_rows(M, lane, valid, Mx, My, mx, my_, H);
-    pf_add(prof, PF_SETUP, pf_now() - ps0);
+    const unsigned long long ps1 = pf_now();
+    pf_add(prof, PF_SETUP, ps1 - ps0);
     int good = 0;
     if (ok) {   // the 16 lanes of the row split the points; integer count, order-free
       float Hf[8];
@@ -962,7 +986,11 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
     good = rsum16(good);
     int* hyp = B.hyp[chunk & 1];
     if (gl == 0) hyp[myh] = (valid ? 0x80000000u : 0u) | (ok ? 0x40000000u : 0u) | (unsigned)good;
+    const unsigned long long ps2 = pf_now();
+    pf_add(prof, PF_COUNT, ps2 - ps1);
     __syncthreads();
+    const unsigned long long ps3 = pf_now();
+    pf_add(prof, PF_BARRIER, ps3 - ps2);
     // sequential replay in sample order (every thread, identically)
     int best_h = -1;
     for (int h = 0; h < HC; h++) {
@@ -987,6 +1015,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
       for (int i = 0; i < 9; i++) S.bestH[i] = H[i];
     }
     chunk++;
+    pf_add(prof, PF_REPLAY, pf_now() - ps3);
   }
   __threadfence_block();
   __syncthreads();
@@ -1328,10 +1357,11 @@ int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A_, int npairs, int
     (void)hipFree(d_prof);
     const double n = h[PF_CALLS] ? (double)h[PF_CALLS] : 1.0;
     fprintf(stderr, "[evh ransac_final prof] calls %llu | per call (cycles): total %.0f hyp %.0f (chunks %.2f, dlt4+jacobi %.0f) "
-            "compact %.0f refit %.0f lm %.0f (iters %.2f, solve8 %.0f, eval %.0f) | rotations: 9x9 %.1f 8x8 %.1f\n",
+            "compact %.0f refit %.0f lm %.0f (iters %.2f, solve8 %.0f, eval %.0f) | rotations: 9x9 %.1f 8x8 %.1f | chunk loop: rng %.0f "
+            "count %.0f barrier %.0f replay %.0f\n",
             h[PF_CALLS], h[PF_TOTAL] / n, h[PF_HYP] / n, h[PF_CHUNKS] / n, h[PF_SETUP] / n, h[PF_COMPACT] / n,
             h[PF_REFIT] / n, h[PF_LM] / n, h[PF_LM_ITERS] / n, h[PF_SOLVE8] / n, h[PF_EVAL] / n, h[PF_ROT9] / n,
-            h[PF_ROT8] / n);
+            h[PF_ROT8] / n, h[PF_RNG] / n, h[PF_COUNT] / n, h[PF_BARRIER] / n, h[PF_REPLAY] / n);
   }
   return EVH_SUCCESS;
 }
