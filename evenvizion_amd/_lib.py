@@ -35,6 +35,8 @@ SIGNATURES = {
     "evh_profile_stage_name": (C.c_char_p, [_i]),
     "evh_resize_area_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _vp, _i, _i, _i64, _i64]),
     "evh_fixed_plane_field": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "evh_superposition_scan": (_i, [_vp, _vp, _i, _vp]),
+    "evh_transform_points": (_i, [_vp, _vp, _i, _vp, _vp, _i, _d, _d, _i, _vp]),
     "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
     "evh_set_fast_lift": (_i, [_vp, _i]),
     "evh_set_fast_share": (_i, [_vp, _i]),
@@ -192,6 +194,24 @@ class Context:
         out = np.zeros(len(Hs), np.float64)
         self._check(self.lib.evh_fixed_plane_field(self.h, _hp(Hs), len(Hs), int(w), int(h),
                                                    field.data_ptr() if field is not None else None, _hp(out)))
+        return out
+
+    # ---- N1 ----
+    def superposition_scan(self, Hs):
+        """Hs f64[n,3,3] per-frame H in frame order -> f64[n,3,3] running superposition (utils.superposition_dict)."""
+        Hs = np.ascontiguousarray(Hs, np.float64).reshape(-1, 9)
+        out = np.zeros_like(Hs)
+        self._check(self.lib.evh_superposition_scan(self.h, _hp(Hs), len(Hs), _hp(out)))
+        return out.reshape(-1, 3, 3)
+
+    def transform_points(self, mats, idx, pts, kx=1.0, ky=1.0, decimals=-1):
+        """pts f64[n,2], idx i32[n] (row of mats f64[m,3,3] per point) -> f64[n,2] transformed (and rounded) points."""
+        mats = np.ascontiguousarray(mats, np.float64).reshape(-1, 9)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+        idx = np.ascontiguousarray(idx, np.int32).reshape(-1)
+        out = np.zeros_like(pts)
+        self._check(self.lib.evh_transform_points(self.h, _hp(mats), len(mats), _hp(idx), _hp(pts), len(pts), float(kx),
+                                                  float(ky), int(decimals), _hp(out)))
         return out
 
     # ---- K1..K6 ----

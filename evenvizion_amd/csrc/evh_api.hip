@@ -402,6 +402,47 @@ int evh_fixed_plane_field(evh_ctx* c, const double* h_Hsup, int n, int w, int h,
   return EVH_SUCCESS;
 }
 
+int evh_superposition_scan(evh_ctx* c, const double* h_H, int n, double* h_out) {
+  if (!c || !h_H || !h_out || n < 1) return evh_fail(c, EVH_ERR_INVALID, "evh_superposition_scan: bad argument");
+  double* d = nullptr;
+  const size_t bytes = sizeof(double) * 9 * (size_t)n;
+  EVH_HIP(c, hipMalloc(&d, 2 * bytes));
+  int rc = EVH_SUCCESS;
+  hipError_t e = hipMemcpyAsync(d, h_H, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = evh_launch_superposition_scan(c, d, n, d + 9 * (size_t)n);
+  if (e == hipSuccess && rc == EVH_SUCCESS) e = hipMemcpyAsync(h_out, d + 9 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("evh_superposition_scan: ") + hipGetErrorString(e));
+  return rc;
+}
+
+int evh_transform_points(evh_ctx* c, const double* h_M, int nmat, const int32_t* h_idx, const double* h_pts, int n, double kx,
+                         double ky, int decimals, double* h_out) {
+  if (!c || !h_M || !h_idx || !h_pts || !h_out || nmat < 1 || n < 0 || decimals > 15)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_transform_points: bad argument");
+  if (n == 0) return EVH_SUCCESS;
+  for (int i = 0; i < n; i++)
+    if (h_idx[i] < 0 || h_idx[i] >= nmat) return evh_fail(c, EVH_ERR_INVALID, "evh_transform_points: matrix index out of range");
+  const size_t bm = sizeof(double) * 9 * (size_t)nmat, bp = sizeof(double) * 2 * (size_t)n, bi = sizeof(int32_t) * (size_t)n;
+  char* d = nullptr;
+  EVH_HIP(c, hipMalloc(&d, bm + 2 * bp + bi));
+  double* d_M = reinterpret_cast<double*>(d);
+  double* d_pts = reinterpret_cast<double*>(d + bm);
+  double* d_out = reinterpret_cast<double*>(d + bm + bp);
+  int* d_idx = reinterpret_cast<int*>(d + bm + 2 * bp);
+  int rc = EVH_SUCCESS;
+  hipError_t e = hipMemcpyAsync(d_M, h_M, bm, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pts, h_pts, bp, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_idx, h_idx, bi, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = evh_launch_transform_points(c, d_M, d_idx, d_pts, n, kx, ky, decimals, d_out);
+  if (e == hipSuccess && rc == EVH_SUCCESS) e = hipMemcpyAsync(h_out, d_out, bp, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("evh_transform_points: ") + hipGetErrorString(e));
+  return rc;
+}
+
 int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
                          int64_t row_stride, int64_t frame_stride, int nfeatures) {
   if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, "evh_orb_detect_batch: NULL argument");

@@ -84,6 +84,52 @@ __global__ __launch_bounds__(256) void k_fixed_plane(const double* __restrict__ 
   }
 }
 
+// N1: utils.superposition_dict (utils.py:184-211) as one sequential scan: out[0] = H[0] (matrix_H_first),
+// out[i] = np.dot(H[i], out[i-1]) / [2][2].  np.dot(3x3, 3x3) = the forward FMA chain pinned by the reference-captured
+// fixtures (tests/golden/glue_goldens.json "sup_false"), the same order k_ransac_final_stream uses.
+__global__ __launch_bounds__(64) void k_superposition_scan(const double* __restrict__ H, int n, double* __restrict__ out) {
+  __shared__ double S[9];
+  const int lane = threadIdx.x;
+  if (lane < 9) { S[lane] = H[lane]; out[lane] = H[lane]; }
+  __syncthreads();
+  for (int i = 1; i < n; i++) {
+    double P = 0;
+    if (lane < 9) {
+      const double* Hi = H + 9 * (int64_t)i;
+      const int r = lane / 3, c = lane - 3 * r;
+      P = fma(Hi[3 * r + 2], S[6 + c], fma(Hi[3 * r + 1], S[3 + c], Hi[3 * r] * S[c]));
+    }
+    const double P8 = __shfl(P, 8);
+    __syncthreads();
+    if (lane < 9) { const double v = P / P8; S[lane] = v; out[9 * (int64_t)i + lane] = v; }
+    __syncthreads();
+  }
+}
+
+// N1: fixed_coordinate_system.from_original_to_fix / from_fix_to_original (fixed_coordinate_system.py:19-69, 72-122)
+// batched: point i -> np.around(np.dot(M[idx[i]], (kx*x, ky*y, 1))[:2] / [2], decimals).  M is H itself or (for the
+// inverse direction) the caller's inverted matrix.  np.dot(3x3, vec) = fma(h0, x, h1*y) + h2 (fixture "hv"); np.around
+// = rint(v * 10^d) / 10^d (half to even); decimals < 0: no rounding.
+__global__ __launch_bounds__(256) void k_transform_points(const double* __restrict__ M, const int* __restrict__ idx,
+                                                          const double* __restrict__ pts, int n, double kx, double ky,
+                                                          int decimals, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* H = M + 9 * (int64_t)idx[i];
+  const double x = kx * pts[2 * i], y = ky * pts[2 * i + 1];
+  const double tx = fma(H[0], x, H[1] * y) + H[2];
+  const double ty = fma(H[3], x, H[4] * y) + H[5];
+  const double tw = fma(H[6], x, H[7] * y) + H[8];
+  double u = tx / tw, v = ty / tw;
+  if (decimals >= 0) {
+    double sc = 1.0;
+    for (int d = 0; d < decimals; d++) sc *= 10.0;
+    u = __builtin_rint(u * sc) / sc;
+    v = __builtin_rint(v * sc) / sc;
+  }
+  out[2 * i] = u; out[2 * i + 1] = v;
+}
+
 struct HostTab { std::vector<int> start, cnt, si; std::vector<float> al; };
 
 void build_area_tab(int ssize, int dsize, double scale, HostTab& t) {
@@ -152,6 +198,19 @@ int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, i
   (void)hipStreamSynchronize(c->stream);  // the pageable upload and the table lifetime both end here
   (void)hipFree(d_blob);
   if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("k_resize_area: ") + hipGetErrorString(e));
+  return EVH_SUCCESS;
+}
+
+int evh_launch_superposition_scan(evh_ctx* c, const double* d_H, int n, double* d_out) {
+  hipLaunchKernelGGL(k_superposition_scan, dim3(1), dim3(64), 0, c->stream, d_H, n, d_out);
+  EVH_HIP(c, hipGetLastError());
+  return EVH_SUCCESS;
+}
+int evh_launch_transform_points(evh_ctx* c, const double* d_M, const int* d_idx, const double* d_pts, int n, double kx,
+                                double ky, int decimals, double* d_out) {
+  hipLaunchKernelGGL(k_transform_points, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_M, d_idx, d_pts, n, kx, ky,
+                     decimals, d_out);
+  EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
 

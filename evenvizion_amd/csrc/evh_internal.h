@@ -120,6 +120,9 @@ int evh_launch_pyramid(evh_ctx* c, int nframes);
 int evh_launch_fast(evh_ctx* c, int nframes, int share_group);
 int evh_launch_select(evh_ctx* c, int nframes);
 int evh_launch_describe(evh_ctx* c, int nframes);
+int evh_launch_superposition_scan(evh_ctx* c, const double* d_H, int n, double* d_out);
+int evh_launch_transform_points(evh_ctx* c, const double* d_M, const int* d_idx, const double* d_pts, int n, double kx,
+                                double ky, int decimals, double* d_out);
 int evh_launch_fixed_plane(evh_ctx* c, const double* d_H, int n, int w, int h, double* d_field, unsigned long long* d_max);
 int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
                            int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,

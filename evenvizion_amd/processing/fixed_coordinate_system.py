@@ -1,26 +1,38 @@
 """Coordinate mapping between original frames and the fixed plane -- counterpart of
-evenvizion/processing/fixed_coordinate_system.py:19-122.  A consumer of the superposed H matrices (O(objects)
-host arithmetic); same names, arguments and 2-decimal rounding as the reference.
+evenvizion/processing/fixed_coordinate_system.py:19-122; same names, arguments and 2-decimal rounding as
+the reference.  All points of a call go through ONE batched device transform (evh_transform_points).
 
 Layouts: coordinates {frame_no: [{"x1": x, "y1": y, ...}, ...]}; homography_dict {frame_no: 3x3 superposed H}.
 """
 from copy import deepcopy
 
 import numpy as np
+import numpy.linalg as linalg
 
-from .utils import homography_transformation, inverse_homography_transformation
+from .. import runtime
 
 
-def _convert(coordinates, homography_dict, kx, ky, transform):
-    result = {}
-    for frame_no, frame_info in coordinates.items():
+def _convert(coordinates, homography_dict, kx, ky, inverse):
+    frames = list(coordinates.keys())
+    mats = [np.asarray(homography_dict[f], np.float64) for f in frames]
+    if inverse:
+        mats = [linalg.inv(m) for m in mats]
+    pts, idx = [], []
+    for i, f in enumerate(frames):
+        for rect in coordinates[f]:
+            pts.append((rect["x1"], rect["y1"]))
+            idx.append(i)
+    out = (runtime.get_context(64, 64, 2, runtime.NFEATURES).transform_points(mats, idx, pts, kx, ky, decimals=2)
+           if pts else np.zeros((0, 2)))
+    result, k = {}, 0
+    for f in frames:
         converted = []
-        for rect in frame_info:
+        for rect in coordinates[f]:
             new_rect = deepcopy(rect)
-            xy = np.around(transform([kx * rect["x1"], ky * rect["y1"]], homography_dict[frame_no]), decimals=2)
-            new_rect["x1"], new_rect["y1"] = xy[0], xy[1]
+            new_rect["x1"], new_rect["y1"] = out[k][0], out[k][1]
             converted.append(new_rect)
-        result[frame_no] = converted
+            k += 1
+        result[f] = converted
     return result
 
 
@@ -29,8 +41,7 @@ def from_original_to_fix(original_coordinates, homography_dict, original_image_s
     apply the frame's superposed H (fixed_coordinate_system.py:56-69)."""
     original_h, original_w = original_image_shape
     resize_h, resize_w = resize_image_shape
-    return _convert(original_coordinates, homography_dict, int(resize_w) / original_w, int(resize_h) / original_h,
-                    homography_transformation)
+    return _convert(original_coordinates, homography_dict, int(resize_w) / original_w, int(resize_h) / original_h, False)
 
 
 def from_fix_to_original(fix_coordinates, homography_dict, original_image_shape, resize_image_shape):
@@ -38,5 +49,4 @@ def from_fix_to_original(fix_coordinates, homography_dict, original_image_shape,
     inverse H (fixed_coordinate_system.py:109-122); kept as is."""
     original_h, original_w = original_image_shape
     resize_h, resize_w = resize_image_shape
-    return _convert(fix_coordinates, homography_dict, original_w / resize_w, original_h / resize_h,
-                    inverse_homography_transformation)
+    return _convert(fix_coordinates, homography_dict, original_w / resize_w, original_h / resize_h, True)

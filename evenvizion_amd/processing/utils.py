@@ -1,8 +1,10 @@
 """Utility functions -- MI355X counterpart of evenvizion/processing/utils.py (same names, arguments, errors).
 
 GPU-backed: compute_homography (utils.py:328-363 -> evh_compute_homography), find_point_displacement +
-get_largest_group_points (utils.py:258-325 -> evh_static_filter when called together through KeyPoints).
-The rest is the reference's small host-side glue (JSON readers, 3x3 products), restated in plain numpy.
+get_largest_group_points (utils.py:258-325 -> evh_static_filter when called together through KeyPoints),
+matrix_superposition / superposition_dict (utils.py:118-145, 184-211 -> evh_superposition_scan),
+homography_transformation / inverse_homography_transformation (utils.py:71-115 -> evh_transform_points; the 3x3
+inverse itself stays numpy.linalg.inv on the host, as in the reference).  The rest is JSON reading.
 """
 import json
 
@@ -32,31 +34,34 @@ def remove_double_matching(pts_a, pts_b):
     return new_pts_a, new_pts_b
 
 
+def _small_context():
+    return runtime.get_context(64, 64, 2, runtime.NFEATURES)
+
+
+def _as_xy(vector):
+    v = np.asarray(vector, np.float64).reshape(-1)
+    if len(v) > 2 and v[2] != 1:
+        raise NotImplementedError("homogeneous input with w != 1 is outside the hot path")
+    return v[:2]
+
+
 def homography_transformation(vector, matrix_H):
-    """utils.py:89-92"""
-    while len(vector) < 3:
-        vector = np.append(vector, [1])
-    new_vector = np.dot(matrix_H, vector)
-    return new_vector[:-1] / new_vector[-1]
+    """(x, y[, 1]) -> np.dot(H, (x, y, 1))[:2] / [2] as float64[2] (utils.py:89-92), on the device."""
+    return _small_context().transform_points(matrix_H, [0], [_as_xy(vector)])[0]
 
 
 def inverse_homography_transformation(vector, matrix_H):
-    """utils.py:112-115"""
-    while len(vector) < 3:
-        vector = np.append(vector, [1])
-    new_vector = np.dot(linalg.inv(matrix_H), vector)
-    return new_vector[:-1] / new_vector[-1]
+    """The same through numpy.linalg.inv(H) (utils.py:112-115)."""
+    return _small_context().transform_points(linalg.inv(np.asarray(matrix_H, np.float64)), [0], [_as_xy(vector)])[0]
 
 
 def matrix_superposition(H, matrix_H_superposition, matrix_H_first=False):
-    """utils.py:139-145"""
-    if H is not None:
-        if matrix_H_first:
-            matrix_H_superposition = H
-        else:
-            matrix_H_superposition = np.dot(H, matrix_H_superposition)
-            matrix_H_superposition = np.divide(matrix_H_superposition, matrix_H_superposition[2][2])
-    return matrix_H_superposition
+    """H . H_sup normalised by its [2][2]; the first H passes through unchanged; H None keeps H_sup (utils.py:139-145)."""
+    if H is None:
+        return matrix_H_superposition
+    if matrix_H_first:
+        return H
+    return _small_context().superposition_scan([matrix_H_superposition, H])[1]
 
 
 def read_homography_dict(path_to_homography_dict):
@@ -71,14 +76,13 @@ def read_homography_dict(path_to_homography_dict):
 
 
 def superposition_dict(homography_dict):
-    """utils.py:203-211"""
+    """{1: identity, frame_no: running superposition of the per-frame H} (utils.py:203-211): one device scan."""
     superposition_homography_dict = {1: [[1, 0, 0], [0, 1, 0], [0, 0, 1]]}
-    matrix_H_next = None
-    H_first = True
-    for frame_no, frame_H in homography_dict.items():
-        matrix_H_next = matrix_superposition(frame_H["H"], matrix_H_next, H_first)
-        H_first = False
-        superposition_homography_dict[frame_no] = matrix_H_next
+    frames = list(homography_dict.keys())
+    if frames:
+        sup = _small_context().superposition_scan([homography_dict[k]["H"] for k in frames])
+        for k, m in zip(frames, sup):
+            superposition_homography_dict[k] = m
     return superposition_homography_dict
 
 

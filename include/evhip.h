@@ -10,6 +10,8 @@
  *   evh_match_knn2_l2u8           DescriptorMatcher("BruteForce").knnMatch(q,t,2)   matching.py:102-108
  *   evh_ratio_unique_filter       lowes_ratio_test + filter_corresponding_points +
  *                                 remove_double_matching                 matching.py:112-119,166-239; utils.py:41-68
+ *   evh_superposition_scan        utils.superposition_dict / matrix_superposition   utils.py:118-145,184-211
+ *   evh_transform_points          from_original_to_fix / from_fix_to_original       fixed_coordinate_system.py:19-122
  *   evh_find_homography_ransac    cv2.findHomography(a,b,cv2.RANSAC,3.0) matching.py:156-157; utils.py:356-358
  *   evh_static_filter             find_point_displacement + get_largest_group_points   utils.py:258-325
  *   evh_pair_homography_batch     the per-pair body of get_homography_dict video_processing.py:67-105
@@ -95,6 +97,18 @@ int evh_resize_area_u8c3(evh_ctx* ctx, const uint8_t* d_src, int sw, int sh, uin
  * the per-frame value whose maximum over the video is written to metrics_file.txt.  d_field (device,
  * f64[n,h,w,2], may be NULL) receives the field; h_max f64[n] the maxima.  Synchronises.                     */
 int evh_fixed_plane_field(evh_ctx* ctx, const double* h_Hsup, int n, int w, int h, double* d_field, double* h_max);
+
+/* ---- N1: the consumers of dict_with_homography_matrix.json ------------------------------------------------ */
+/* utils.superposition_dict (utils.py:184-211): h_H f64[n,9] = the per-frame H in frame order -> h_out f64[n,9] the running
+ * superposition: out[0] = H[0], out[i] = np.dot(H[i], out[i-1]) / [2][2] (matrix_superposition, utils.py:139-145; with
+ * n = 2 it is one matrix_superposition(H[1], H[0], False)).  Sequential scan on the device.  Synchronises.            */
+int evh_superposition_scan(evh_ctx* ctx, const double* h_H, int n, double* h_out);
+/* fixed_coordinate_system.from_original_to_fix / from_fix_to_original (fixed_coordinate_system.py:19-69, 72-122) and
+ * utils.homography_transformation (utils.py:89-92), batched: point i = (x, y) of h_pts f64[n,2] ->
+ * np.around(np.dot(M[h_idx[i]], (kx*x, ky*y, 1))[:2] / [2], decimals) into h_out f64[n,2]; h_M f64[nmat,9] holds the
+ * superposed H per frame (or, for the inverse direction, their inverses); decimals < 0: no rounding.  Synchronises. */
+int evh_transform_points(evh_ctx* ctx, const double* h_M, int nmat, const int32_t* h_idx, const double* h_pts, int n,
+                         double kx, double ky, int decimals, double* h_out);
 
 /* ---- K1..K6: ORB detectAndCompute on a batch of frames ------------------------------------------------------- */
 /* channels: 1 (gray) or 3 (BGR, converted like cvtColor(BGR2GRAY)).  Results stay resident in the context

@@ -1,5 +1,7 @@
-"""Host-side mirror of evenvizion.processing (evenvizion_amd/processing) against the golden vectors captured from
-the reference's own functions; these paths are pure host glue and run without a GPU."""
+"""Mirror of evenvizion.processing (evenvizion_amd/processing) against the golden vectors captured from the
+reference's own functions.  The pure host glue runs without a GPU; the N1 consumers (superposition_dict,
+matrix_superposition, homography_transformation, from_original_to_fix / from_fix_to_original) go through the device
+entries evh_superposition_scan / evh_transform_points and are marked gpu."""
 import json
 import os
 
@@ -54,6 +56,7 @@ def test_remove_double_and_static_filter(goldens):
         assert np.array_equal(sa, np.float32(c["out_a"]).reshape(-1, 2)) and np.array_equal(sb, np.float32(c["out_b"]).reshape(-1, 2))
 
 
+@pytest.mark.gpu
 def test_superposition_and_transform(goldens):
     for c in goldens["matrix_superposition"]:
         H, S = np.array(c["H"]), np.array(c["S"])
@@ -62,6 +65,7 @@ def test_superposition_and_transform(goldens):
         assert utils.homography_transformation(np.float32(c["v"]), H).tolist() == c["hv"]
 
 
+@pytest.mark.gpu
 def test_kat_f12_through_the_mirror(goldens):
     hd, ri = utils.read_homography_dict(os.path.join(GOLD, "ref_dict_with_homography_matrix.json"))
     sup = utils.superposition_dict(hd)
@@ -73,8 +77,10 @@ def test_kat_f12_through_the_mirror(goldens):
         d = Hk[2, 0] * xs + Hk[2, 1] * ys + Hk[2, 2]
         mx.append(max(((Hk[0, 0] * xs + Hk[0, 1] * ys + Hk[0, 2]) / d).max(), ((Hk[1, 0] * xs + Hk[1, 1] * ys + Hk[1, 2]) / d).max()))
     assert max(mx[:-1]) == 863.0428982580879 == float(open(os.path.join(GOLD, "ref_metrics_file.txt")).read().split(":")[1])
+    assert np.array_equal(np.asarray(sup[list(sup)[-1]]), np.array(goldens["kat_f12"]["sup_last"]))     # device scan == reference, bit for bit
 
 
+@pytest.mark.gpu
 def test_fixed_coordinates(goldens):
     g = goldens["fixed_coordinates"]
     hd, _ = utils.read_homography_dict(os.path.join(GOLD, "ref_dict_with_homography_matrix.json"))

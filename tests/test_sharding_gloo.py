@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -113,3 +114,83 @@ def test_sharded_stream_world2():
         for p in procs:
             p.join(60)
         assert res == [(0, True), (1, True)]
+
+
+# ---- bench.py's gather (one all_gather_into_tensor of the per-pair f64 H records per step) ---------------------------
+def _bench_gather_worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H = torch.full((B, 9), float(rank + 1), dtype=torch.float64) + torch.arange(B, dtype=torch.float64)[:, None]
+    gathered = torch.zeros(world * B, 9, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, H)
+    want = torch.cat([torch.full((B, 9), float(r + 1), dtype=torch.float64) + torch.arange(B, dtype=torch.float64)[:, None]
+                      for r in range(world)])
+    q.put((rank, bool(torch.equal(gathered, want))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gather_path_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_gather_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+# ---- the same two paths over RCCL on real devices: needs two GPUs (the driver's 8-GPU node; skipped on a 1-GPU box) ----
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      LOCAL_RANK=str(rank), RANK=str(rank), WORLD_SIZE=str(world))
+    import numpy as np
+    from evenvizion_amd import synthetic as S
+    from evenvizion_amd._lib import Context
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    frames, _ = S.make_stream(5, 7, 400, 224)
+    n = len(frames)
+    c = Context(device=rank, max_w=400, max_h=224, max_features=500, max_frames=n)
+    d = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+
+    def static_fn(f_lo, f_hi):
+        return c.stream_static_batch(d[f_lo:f_hi])
+
+    def scan_fn(rows, counts, st1):
+        return c.stream_scan(rows, counts, st1)
+
+    H, st = sharded_stream_homographies(static_fn, scan_fn, n)
+    Hw = torch.zeros(n - 1, 9, dtype=torch.float64, device=dev); sw = torch.zeros(n - 1, dtype=torch.int32, device=dev)
+    c.stream_homography_batch(d, Hw, sw)
+    c.synchronize(); torch.cuda.synchronize(dev)
+    ok = bool(torch.equal(H, Hw) and torch.equal(st, sw))
+    gathered = torch.zeros(world * (n - 1), 9, dtype=torch.float64, device=dev)     # bench.py's gather of the H records
+    dist.all_gather_into_tensor(gathered, Hw)
+    ok = ok and bool(torch.equal(gathered[:n - 1], Hw) and torch.equal(gathered[n - 1:], Hw))
+    q.put((rank, ok))
+    dist.barrier()
+    c.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_stream_and_gather_nccl_world2():
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (RCCL world_size 2); this box exposes %d" %
+                    (torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+    assert res == [(0, True), (1, True)]
