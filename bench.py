@@ -80,6 +80,7 @@ def parse_args():
     ap.add_argument("--no-temporal", action="store_true", help="switch off the two exact shortcuts that lean on consecutive frames / calls looking alike (threshold sharing inside a pair, threshold hint across calls) for the MAIN timed loop")
     ap.add_argument("--force-max-iters", action="store_true", help="stream configs: evaluate all 2000 RANSAC samples (fixed-iteration stress variant)")
     ap.add_argument("--smooth", type=int, default=0, help="3x3 box-blur passes over the synthetic frames (content with fewer, weaker corners; informational)")
+    ap.add_argument("--gen-procs", type=int, default=0, help="host processes that generate the synthetic pairs (0 = auto; use 1 under rocprofv3: no child processes)")
     ap.add_argument("--contexts", type=int, default=1, help="independent contexts/streams the steps alternate over (pair configs)")
     args = ap.parse_args()
     cfg = {1: dict(kind="pairs", w=1280, h=720, nfeat=500, pairs=1024, steps=10),
@@ -116,12 +117,13 @@ def _make_pair_job(a):
     return synthetic.make_pair(*a)
 
 
-def make_unique_pairs(config_seed, U, w, h):
+def make_unique_pairs(config_seed, U, w, h, nproc=0):
     """U distinct synthetic pairs (SURVEY 8d seeds 1000*config + pair index), generated on the host cores in parallel."""
     import multiprocessing as mp
     jobs = [(1000 * config_seed + p, w, h) for p in range(U)]
-    nproc = min(U, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8,
-                16 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 8)
+    if nproc <= 0:
+        nproc = min(U, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8,
+                    16 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 8)
     if nproc > 1:
         with mp.get_context("spawn").Pool(nproc) as pool:
             res = pool.map(_make_pair_job, jobs)
@@ -149,7 +151,7 @@ def main():
     from evenvizion_amd import synthetic
     if args.kind == "pairs":
         U = max(1, min(args.unique, B))
-        gray = make_unique_pairs(2, U, w, h)
+        gray = make_unique_pairs(2, U, w, h, args.gen_procs)
         for _ in range(max(args.smooth, 0)):                     # informational: lower-contrast, corner-poor content
             g = np.pad(gray.astype(np.uint16), ((0, 0), (1, 1), (1, 1)), mode="edge")
             acc = sum(g[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3))

@@ -636,7 +636,7 @@ __global__ void k_fast_thr(FastArgs A, int nframes) {
   const int mod = A.samp_mod[l];
   int T = EVH_FAST_THR;
   if (mod > 0 && L.quota > 0) {
-    const int need = max(24, (8 * L.quota + mod - 1) / mod);   // 4x the 2*quota corners the level must deliver
+    const int need = max(24, (6 * L.quota + mod - 1) / mod);   // 3x the 2*quota corners the level must deliver (8: +3 % FAST time)
     const int f = i / EVH_NLEVELS;
     const int src = (A.share_group > 0 && ((f % A.share_group) & 1)) ? i - EVH_NLEVELS : i;
     const unsigned* h = A.shist + (int64_t)src * 256;
