@@ -408,12 +408,8 @@ __device__ __forceinline__ int jacobi_one(RowMat& M, int lane) {
 }
 
 // de-normalise the smallest-eigenvalue eigenvector into H (runKernel's tail)
-__device__ __forceinline__ void dlt_finish(const RowMat& M, double cmx, double cmy, double smx, double smy, double cMx,
-                                           double cMy, double sMx, double sMy, double* H) {
-  double H0[9];
-  const int r8 = M.ord[8];
-#pragma unroll
-  for (int i = 0; i < 9; i++) H0[i] = M.V[r8 * MS + i];
+__device__ __forceinline__ void dlt_finish_from(const double* H0, double cmx, double cmy, double smx, double smy, double cMx,
+                                                double cMy, double sMx, double sMy, double* H) {
   const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
   const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
   double Ht[9], H1[9];
@@ -430,6 +426,14 @@ __device__ __forceinline__ void dlt_finish(const RowMat& M, double cmx, double c
   double inv = 1. / H1[8];
 #pragma unroll
   for (int i = 0; i < 9; i++) H[i] = H1[i] * inv;
+}
+__device__ __forceinline__ void dlt_finish(const RowMat& M, double cmx, double cmy, double smx, double smy, double cMx,
+                                           double cMy, double sMx, double sMy, double* H) {
+  double H0[9];
+  const int r8 = M.ord[8];
+#pragma unroll
+  for (int i = 0; i < 9; i++) H0[i] = M.V[r8 * MS + i];
+  dlt_finish_from(H0, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
 }
 
 // one entry (j, k) of L^T L contributed by a normalised correspondence (x, y) <- (X, Y)
@@ -486,6 +490,187 @@ __device__ __forceinline__ bool dlt4_rows(RowMat& M, int lane, bool valid, const
   WSYNC();
   jacobi_rows<9>(M, lane, ok);
   if (ok) dlt_finish(M, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
+  return ok;
+}
+
+
+// ---- one 9x9 eigen-problem PER LANE (fixed-iteration RANSAC: thousands of hypotheses, throughput matters, latency does
+// not): the serial algorithm as it stands, 64 problems side by side.  Every lane's matrices live in LDS as
+// [element][lane] (512 bytes between elements: whatever element a lane picks, it stays on its own banks).
+// Elements: 0..35 upper off-diagonal of A (row i starts at i(17-i)/2), 36..44 W, 45..125 V (rows).  indR / indC are
+// one register per index.  The rescans of indR / indC for the two rotated indices run inside the
+// rotation loop on the freshly rotated values (ascending index, strict '<': the first maximum, as the reference).
+#define LM_ELEMS 126
+#define LM_W 36
+#define LM_V 45
+__device__ __forceinline__ int lm_arow(int i) { return (i * (17 - i)) >> 1; }          // first element of row i (j = i+1)
+__device__ __forceinline__ int lm_a(int i, int j) { return lm_arow(i) + j - i - 1; }     // i < j
+// L = this lane's column: element e at L[e * 64].  A (upper) and W (diagonal) hold the input.  Returns the row of V
+// that belongs to the smallest eigenvalue under the reference's selection sort.
+__device__ __forceinline__ int jacobi_lanes9(double* L, bool active) {
+  const int N = 9;
+#define EL(e) L[(e) * NL]
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j < N; j++) EL(LM_V + i * N + j) = i == j ? 1.0 : 0.0;
+  }
+  int indR[9], indC[9];                // one register each (static index in every loop below)
+#pragma unroll
+  for (int k = 0; k < N; k++) { indR[k] = k < N - 1 ? k + 1 : 0; indC[k] = 0; }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      if (k < N - 1) {
+        int m = k + 1; double mv = fabs(EL(lm_a(k, k + 1)));
+#pragma unroll
+        for (int i = k + 2; i < N; i++) { const double v = fabs(EL(lm_a(k, i))); if (mv < v) mv = v, m = i; }
+        indR[k] = m;
+      }
+      if (k > 0) {
+        int m = 0; double mv = fabs(EL(lm_a(0, k)));
+#pragma unroll
+        for (int i = 1; i < k; i++) { const double v = fabs(EL(lm_a(i, k))); if (mv < v) mv = v, m = i; }
+        indC[k] = m;
+      }
+    }
+  }
+  // the short divide / square-root sequences need every |a_ij| < 2^300 (see jacobi_rows); one lane out of range sends
+  // the wave through the plain forms
+  unsigned amax = 0;
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < LM_V; e++) amax = max(amax, hi32(EL(e)) & 0x7FFFFFFFu);
+  }
+  const bool plain = __ballot(active && amax >= 0x52B00000u) != 0ull;
+  bool act = active;
+  for (int iters = 0; iters < N * N * 30; iters++) {
+    if (__ballot(act) == 0ull) break;
+    // pivot: rows 0..7 through indR, then columns 1..8 through indC; first maximum.  All sixteen candidates are
+    // loaded first (one LDS latency), then compared in order.
+    int ci[16]; double cvv[16];
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) { ci[i] = indR[i]; cvv[i] = EL(lm_arow(i) + ci[i] - i - 1); }
+#pragma unroll
+    for (int i = 1; i < N; i++) { ci[7 + i] = indC[i]; cvv[7 + i] = EL(lm_arow(ci[7 + i]) + i - ci[7 + i] - 1); }
+    int k = 0, l = ci[0];
+    double p = cvv[0], mv = fabs(p);
+#pragma unroll
+    for (int i = 1; i < N - 1; i++) {
+      const bool b = mv < fabs(cvv[i]);
+      mv = b ? fabs(cvv[i]) : mv; p = b ? cvv[i] : p; k = b ? i : k; l = b ? ci[i] : l;
+    }
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+      const bool b = mv < fabs(cvv[7 + i]);
+      mv = b ? fabs(cvv[7 + i]) : mv; p = b ? cvv[7 + i] : p; k = b ? ci[7 + i] : k; l = b ? i : l;
+    }
+    if (mv <= DBL_EPSILON) act = false;
+    k = act ? k : 0; l = act ? l : 1;
+    const int rowk = lm_arow(k), rowl = lm_arow(l);
+    // operands of the rotation: the pairs of A (dummy element 0 for i == k, l) and of V, loaded before the scalars
+    int e1[9], e2[9];
+    double a0[9], b0[9], va[9], vb[9];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const bool rot = i != k && i != l;
+      e1[i] = rot ? (i < k ? lm_arow(i) + k - i - 1 : rowk + i - k - 1) : 0;
+      e2[i] = rot ? (i < l ? lm_arow(i) + l - i - 1 : rowl + i - l - 1) : 0;
+      a0[i] = EL(e1[i]); b0[i] = EL(e2[i]);
+      va[i] = EL(LM_V + k * N + i); vb[i] = EL(LM_V + l * N + i);
+    }
+    const double wk = EL(LM_W + k), wl = EL(LM_W + l);
+    double c = 1, sn = 0, t = 0;
+    if (plain) { const Cst r = rotation_scalars_plain(p, wk, wl); c = r.c; sn = r.s; t = r.t; }
+    else rotation_scalars(p, wk, wl, c, sn, t);
+    // rotate; the rescans of indR / indC for k and l run on the fresh values: row k right of the diagonal holds
+    // A[k][l] = 0 at index l, column l above the diagonal holds it at index k
+    int mRk = 0, mCk = 0, mRl = 0, mCl = 0;
+    double vRk = -1, vCk = -1, vRl = -1, vCl = -1;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const bool rot = i != k && i != l;
+      const double u = rot ? a0[i] * c - b0[i] * sn : 0.0, v = rot ? a0[i] * sn + b0[i] * c : 0.0;
+      if (act && rot) { EL(e1[i]) = u; EL(e2[i]) = v; }
+      const double au = fabs(u), av = fabs(v);
+      const bool rk = i > k && vRk < au, ck = i < k && vCk < au, rl = i > l && vRl < av, cl = i < l && vCl < av;
+      vRk = rk ? au : vRk; mRk = rk ? i : mRk;
+      vCk = ck ? au : vCk; mCk = ck ? i : mCk;
+      vRl = rl ? av : vRl; mRl = rl ? i : mRl;
+      vCl = cl ? av : vCl; mCl = cl ? i : mCl;
+    }
+    if (act) {
+      EL(rowk + l - k - 1) = 0.0;
+      EL(LM_W + k) = wk - t; EL(LM_W + l) = wl + t;
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        EL(LM_V + k * N + i) = va[i] * c - vb[i] * sn;
+        EL(LM_V + l * N + i) = va[i] * sn + vb[i] * c;
+      }
+    }
+    // indR / indC of the two rotated indices (row N-1 has no indR, column 0 no indC: those registers are never read)
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      indR[i] = act && i == k ? mRk : act && i == l ? mRl : indR[i];
+      indC[i] = act && i == k ? mCk : act && i == l ? mCl : indC[i];
+    }
+  }
+  // selection sort (descending) on the index list: only the row that ends last is needed
+  double w[9]; int pm[9];
+#pragma unroll
+  for (int i = 0; i < N; i++) { w[i] = active ? EL(LM_W + i) : 0.0; pm[i] = i; }
+#pragma unroll
+  for (int a = 0; a < N - 1; a++) {
+    double bv = w[a]; int bi = a, bp = pm[a];
+#pragma unroll
+    for (int i = a + 1; i < N; i++) if (bv < w[i]) bv = w[i], bi = i, bp = pm[i];
+#pragma unroll
+    for (int i = a + 1; i < N; i++) if (i == bi) { w[i] = w[a]; pm[i] = pm[a]; }
+    w[a] = bv; pm[a] = bp;
+  }
+  return pm[N - 1];
+#undef EL
+}
+
+// normalised DLT of this LANE's own 4 correspondences (M -> m); returns whether a model was produced
+__device__ __forceinline__ bool dlt4_lane(double* L, bool valid, const float* Mx, const float* My, const float* mx,
+                                          const float* my, double* H) {
+  double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { cmx += mx[i]; cmy += my[i]; cMx += Mx[i]; cMy += My[i]; }
+  cmx /= 4; cmy /= 4; cMx /= 4; cMy /= 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    smx += fabs(mx[i] - cmx); smy += fabs(my[i] - cmy);
+    sMx += fabs(Mx[i] - cMx); sMy += fabs(My[i] - cMy);
+  }
+  const bool ok = valid && !(fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON ||
+                             fabs(sMy) < DBL_EPSILON);
+  if (ok) {
+    smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
+    double x[4], y[4], X[4], Y[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      x[i] = (mx[i] - cmx) * smx; y[i] = (my[i] - cmy) * smy; X[i] = (Mx[i] - cMx) * sMx; Y[i] = (My[i] - cMy) * sMy;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+#pragma unroll
+      for (int k = j; k < 9; k++) {
+        double acc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc += ltl_term(j, k, x[i], y[i], X[i], Y[i]);
+        L[(j == k ? LM_W + j : lm_a(j, k)) * NL] = acc;
+      }
+  }
+  const int r8 = jacobi_lanes9(L, ok);
+  if (ok) {
+    double H0[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) H0[i] = L[(LM_V + r8 * 9 + i) * NL];
+    dlt_finish_from(H0, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
+  }
   return ok;
 }
 
@@ -897,23 +1082,27 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
   return iter;
 }
 
-template <int NW>
+// LANES: the hypothesis phase gives every LANE its own hypothesis (jacobi_lanes9) instead of every 16-lane row -- the
+// fixed-iteration mode, where thousands of hypotheses are evaluated and throughput counts; 63 KB of LDS per wave.
+template <int NW, bool LANES>
 struct BlockLds {
-  RowMat m[NW][NG];
+  RowMat m[LANES ? 1 : NW][NG];
   SolveLds s;
-  int hyp[2][NW * NG];    // per hypothesis of a chunk: valid << 31 | model << 30 | inlier count (double-buffered)
+  int hyp[2][LANES ? NW * NL : NW * NG];    // per hypothesis of a chunk: valid << 31 | model << 30 | inlier count (double-buffered)
   double Hsup[9], Hprev[9], Hcur[9];
   int have_prev, gate;
-  unsigned hist[HB];      // static filter: population and first member of every displacement bin
-  unsigned first[HB];
+  union {
+    struct { unsigned hist[HB]; unsigned first[HB]; } h;   // static filter: population and first member of every bin
+    double lmat[LANES ? NW * LM_ELEMS * NL : 1];            // the per-lane matrices (dead when the static filter runs)
+  } u;
   unsigned long long red[NW];
 };
 
 // ---- cv2.findHomography(a, b, RANSAC, thr) on `n` rows; result in B.s.H (LDS), mask[n] in global.  All NW*64
 // threads of the workgroup call this; the return value is uniform.  scratch: crow = float rows [n][4] for the
 // compacted inliers.  Ends with a workgroup barrier.
-template <int NW>
-__device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const float* rows, int n, double thr, int maxItersArg, double conf,
+template <int NW, bool LANES>
+__device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, const float* rows, int n, double thr, int maxItersArg, double conf,
                                       int force_max, uint8_t* mask, float* crow, int* info, unsigned long long* prof) {
   const unsigned long long pf0 = pf_now();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15;
@@ -934,9 +1123,8 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
     return S.ib[2] != 0;
   }
   const float t = (float)(thr * thr);
-  const int HC = NW * NG;                 // hypotheses per chunk
-  const int myh = wave * NG + row;
-  RowMat& M = B.m[wave][row];
+  const int HC = LANES ? NW * NL : NW * NG;                 // hypotheses per chunk
+  const int myh = LANES ? wave * NL + lane : wave * NG + row;
   Rng rng;
   const FastMod fm((unsigned)n);
   int niters = max(maxItersArg, 1), maxGood = 0, iter = 0, run = 0, chunk = 0;
@@ -946,18 +1134,13 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
     const unsigned long long pr0 = pf_now();
     int my[4] = {0, 1, 2, 3};
     for (int h = 0; h < HC; h++) {
-      int q[4];
-      for (int i = 0; i < 4;) {
-        int idx_i;
-        for (;;) {
-          idx_i = q[i] = (int)fm.mod(rng.next());
-          int j = 0;
-          for (; j < i; j++) if (idx_i == q[j]) break;
-          if (j == i) break;
-        }
-        i++;
-      }
-      if (h == myh) { my[0] = q[0]; my[1] = q[1]; my[2] = q[2]; my[3] = q[3]; }
+      // four distinct indices, a duplicate is redrawn (getSubset's inner loop, straight-line)
+      const int q0 = (int)fm.mod(rng.next());
+      int q1, q2, q3;
+      do q1 = (int)fm.mod(rng.next()); while (q1 == q0);
+      do q2 = (int)fm.mod(rng.next()); while (q2 == q0 || q2 == q1);
+      do q3 = (int)fm.mod(rng.next()); while (q3 == q0 || q3 == q1 || q3 == q2);
+      if (h == myh) { my[0] = q0; my[1] = q1; my[2] = q2; my[3] = q3; }
     }
     float Mx[4], My[4], mx[4], my_[4];
 #pragma unroll
@@ -969,23 +1152,38 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
     double H[9];
     const unsigned long long ps0 = pf_now();
     pf_add(prof, PF_RNG, ps0 - pr0);
-    const bool ok = dlt4_rows(M, lane, valid, Mx, My, mx, my_, H);
+    bool ok;
+    if constexpr (LANES) ok = dlt4_lane(B.u.lmat + (wave * LM_ELEMS * NL + lane), valid, Mx, My, mx, my_, H);
+    else ok = dlt4_rows(B.m[wave][row], lane, valid, Mx, My, mx, my_, H);
     const unsigned long long ps1 = pf_now();
     pf_add(prof, PF_SETUP, ps1 - ps0);
     int good = 0;
-    if (ok) {   // the 16 lanes of the row split the points; integer count, order-free
+    {
       float Hf[8];
 #pragma unroll
-      for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+      for (int i = 0; i < 8; i++) Hf[i] = ok ? (float)H[i] : 0.f;
+      if constexpr (LANES) {   // every lane walks all points (same addresses across the wave: one transaction each)
+        if (__ballot(ok) != 0ull) {
 #pragma unroll 4
-      for (int i = gl; i < n; i += GL) {
-        const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
-        good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
+          for (int i = 0; i < n; i++) {
+            const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+            good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
+          }
+        }
+        if (!ok) good = 0;
+      } else {
+        if (ok) {   // the 16 lanes of the row split the points; integer count, order-free
+#pragma unroll 4
+          for (int i = gl; i < n; i += GL) {
+            const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+            good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
+          }
+        }
+        good = rsum16(good);
       }
     }
-    good = rsum16(good);
     int* hyp = B.hyp[chunk & 1];
-    if (gl == 0) hyp[myh] = (valid ? 0x80000000u : 0u) | (ok ? 0x40000000u : 0u) | (unsigned)good;
+    if (LANES || gl == 0) hyp[myh] = (valid ? 0x80000000u : 0u) | (ok ? 0x40000000u : 0u) | (unsigned)good;
     const unsigned long long ps2 = pf_now();
     pf_add(prof, PF_COUNT, ps2 - ps1);
     __syncthreads();
@@ -1010,7 +1208,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW>& B, const flo
         if (!force_max) niters = update_num_iters(conf, (double)(n - g) / n, 4, niters);
       }
     }
-    if (best_h == myh && gl == 0) {
+    if (best_h == myh && (LANES || gl == 0)) {
 #pragma unroll
       for (int i = 0; i < 9; i++) S.bestH[i] = H[i];
     }
@@ -1072,11 +1270,11 @@ __device__ __forceinline__ void hdot(const double* H, double x, double y, double
 
 // find_point_displacement + get_largest_group_points; rbin = int scratch [n] (global); returns kept count (uniform).
 // All threads of the workgroup; ends with a workgroup barrier.
-template <int NW>
-__device__ __forceinline__ int static_filter_block(BlockLds<NW>& B, const double* H /*LDS*/, const float* rows, int n, int* rbin,
+template <int NW, bool LANES>
+__device__ __forceinline__ int static_filter_block(BlockLds<NW, LANES>& B, const double* H /*LDS*/, const float* rows, int n, int* rbin,
                                    float* out) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NT = NW * NL;
-  for (int i = tid; i < HB; i += NT) { B.hist[i] = 0u; B.first[i] = 0xFFFFFFFFu; }
+  for (int i = tid; i < HB; i += NT) { B.u.h.hist[i] = 0u; B.u.h.first[i] = 0xFFFFFFFFu; }
   __syncthreads();
   int big = 0;
   for (int i = tid; i < n; i += NT) {
@@ -1086,7 +1284,7 @@ __device__ __forceinline__ int static_filter_block(BlockLds<NW>& B, const double
     double dist = sqrt(dx * dx + dy * dy);
     const int r = (int)__builtin_rint(dist);  // Python round(): half to even
     rbin[i] = r;
-    if ((unsigned)r < (unsigned)HB) { atomicAdd(&B.hist[r], 1u); atomicMin(&B.first[r], (unsigned)i); }
+    if ((unsigned)r < (unsigned)HB) { atomicAdd(&B.u.h.hist[r], 1u); atomicMin(&B.u.h.first[r], (unsigned)i); }
     else big = 1;
   }
   __threadfence_block();
@@ -1096,9 +1294,9 @@ __device__ __forceinline__ int static_filter_block(BlockLds<NW>& B, const double
   unsigned long long bestkey = 0;
   if (!big) {
     for (int b = tid; b < HB; b += NT) {
-      const unsigned cnt = B.hist[b];
+      const unsigned cnt = B.u.h.hist[b];
       if (cnt) {
-        const unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0x7FFFFFFF - (int)B.first[b]);
+        const unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0x7FFFFFFF - (int)B.u.h.first[b]);
         bestkey = key > bestkey ? key : bestkey;
       }
     }
@@ -1145,8 +1343,8 @@ __device__ __forceinline__ int static_filter_block(BlockLds<NW>& B, const double
 
 // compute_homography (utils.py:351-362): optional pre-transform by Hsup (f64 -> f32), RANSAC #2, 0.7 gate.
 // All threads; uniform result; ends with a workgroup barrier.
-template <int NW>
-__device__ __forceinline__ int compute_homography_block(BlockLds<NW>& B, const float* rows, int n, const double* Hsup /*LDS|null*/,
+template <int NW, bool LANES>
+__device__ __forceinline__ int compute_homography_block(BlockLds<NW, LANES>& B, const float* rows, int n, const double* Hsup /*LDS|null*/,
                                         const EvhRansacArgs& A, uint8_t* mask, float* trow, float* crow, int* info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* use = rows;
@@ -1163,7 +1361,7 @@ __device__ __forceinline__ int compute_homography_block(BlockLds<NW>& B, const f
     __syncthreads();
     use = trow;
   }
-  const bool found = find_homography_block<NW>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
+  const bool found = find_homography_block<NW, LANES>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
   if (wave == 0) {
     int s = 0;
     for (int i = lane; i < n; i += NL) s += mask[i];
@@ -1176,39 +1374,39 @@ __device__ __forceinline__ int compute_homography_block(BlockLds<NW>& B, const f
   return EVH_PAIR_OK;
 }
 
-template <int NW>
-__device__ __forceinline__ BlockLds<NW>& block_lds() {
-  __shared__ BlockLds<NW> g;
+template <int NW, bool LANES>
+__device__ __forceinline__ BlockLds<NW, LANES>& block_lds() {
+  __shared__ BlockLds<NW, LANES> g;
   return g;
 }
 
 // generic single-problem entry (evh_find_homography_ransac)
-template <int NW>
+template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_find_homography(EvhRansacArgs A) {
-  BlockLds<NW>& B = block_lds<NW>();
+  BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
   const int tid = threadIdx.x;
   const int n = A.n_fixed;
-  const bool found = find_homography_block<NW>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info, A.prof);
+  const bool found = find_homography_block<NW, LANES>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info, A.prof);
   if (tid < 9) A.H[tid] = found ? B.s.H[tid] : 0.0;
   if (tid == 0) A.found[0] = found ? 1 : 0;
 }
 
 // generic static filter entry
-template <int NW>
+template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_static_filter(const double* H, const float* rows, int n, int* rbin,
                                                            float* out, int* count) {
-  BlockLds<NW>& B = block_lds<NW>();
+  BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
   const int tid = threadIdx.x;
   if (tid < 9) B.s.H[tid] = H[tid];
   __syncthreads();
-  const int m = static_filter_block<NW>(B, B.s.H, rows, n, rbin, out);
+  const int m = static_filter_block<NW, LANES>(B, B.s.H, rows, n, rbin, out);
   if (tid == 0) count[0] = m;
 }
 
 // phase 1 of a pair: RANSAC #1 on the matched rows, then the static-point filter (matching.py:152-163)
-template <int NW>
+template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_ransac_static(EvhRansacArgs A) {
-  BlockLds<NW>& B = block_lds<NW>();
+  BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
   const int p = blockIdx.x, tid = threadIdx.x;
   if (A.status[p] != EVH_PAIR_OK) { if (tid == 0) A.npts2[p] = 0; return; }
   const int n = A.npts[p];
@@ -1218,26 +1416,26 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_static(EvhRansacArgs A) {
   float* crow = A.crow + (int64_t)p * A.row_stride * 4;
   int* rbin = reinterpret_cast<int*>(A.lm + (int64_t)p * A.row_stride * 4);
   int* info = A.info ? A.info + 8 * p : nullptr;
-  const bool found = find_homography_block<NW>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
+  const bool found = find_homography_block<NW, LANES>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
   if (!found) {
     if (tid == 0) { A.status[p] = EVH_PAIR_NO_PROVISIONAL_H; A.npts2[p] = 0; }
     return;
   }
   if (A.H1 && tid < 9) A.H1[9 * p + tid] = B.s.H[tid];
-  const int m = static_filter_block<NW>(B, B.s.H, rows, n, rbin, out);
+  const int m = static_filter_block<NW, LANES>(B, B.s.H, rows, n, rbin, out);
   if (tid == 0) A.npts2[p] = m;
 }
 
 // phase 2: compute_homography.  Independent pairs: one workgroup per pair, Hsup = None.
-template <int NW>
+template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_ransac_final_pairs(EvhRansacArgs A) {
-  BlockLds<NW>& B = block_lds<NW>();
+  BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
   const int p = blockIdx.x, tid = threadIdx.x;
   int st = A.status[p];
   if (st == EVH_PAIR_OK) {
     const int n = A.npts2[p];
     const float* rows = A.pts2 + (int64_t)p * A.row_stride * 4;
-    st = compute_homography_block<NW>(B, rows, n, nullptr, A, A.mask + (int64_t)p * A.row_stride,
+    st = compute_homography_block<NW, LANES>(B, rows, n, nullptr, A, A.mask + (int64_t)p * A.row_stride,
                                       A.pts + (int64_t)p * A.row_stride * 4 /* matched rows are dead: scratch */,
                                       A.crow + (int64_t)p * A.row_stride * 4, A.info ? A.info + 8 * p + 4 : nullptr);
   }
@@ -1247,11 +1445,11 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_pairs(EvhRansacArgs A)
 
 // phase 2, stream semantics (video_processing.py:83-105): sequential scan over the pairs of one stream with the
 // running superposition; a failed pair repeats the previous H (none_H_processing=True).
-template <int NW>
+template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A, int npairs, int pitch) {
   // one workgroup per stream: block s scans the npairs pairs whose per-pair slots start at s * pitch (several streams
   // of one batch sit `pitch` pair slots apart); H / status are written compactly at s * npairs + p
-  BlockLds<NW>& B = block_lds<NW>();
+  BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
   const int tid = threadIdx.x, s = blockIdx.x;
   const double* Hsup0 = A.Hsup0 ? A.Hsup0 + 18 * s : nullptr;
   const double* Hprev0 = A.Hprev0 ? A.Hprev0 + 18 * s : nullptr;
@@ -1269,7 +1467,7 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A
       const int n = A.npts2[slot0 + p];
       const float* rows = A.pts2 + (slot0 + p) * A.row_stride * 4;
       // the scan is sequential: one pair's worth of scratch (the stream's first slot) serves all its pairs
-      st = compute_homography_block<NW>(B, rows, n, first ? nullptr : B.Hsup, A, A.mask + slot0 * A.row_stride,
+      st = compute_homography_block<NW, LANES>(B, rows, n, first ? nullptr : B.Hsup, A, A.mask + slot0 * A.row_stride,
                                         A.pts + slot0 * A.row_stride * 4, A.crow + slot0 * A.row_stride * 4,
                                         A.info ? A.info + 8 * (slot0 + p) + 4 : nullptr);
     }
@@ -1303,20 +1501,20 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A
 }
 
 // waves per workgroup: enough rows to cover the handful of hypotheses an adaptive RANSAC needs in one chunk when the
-// launch is small (latency), one wave per pair when the launch fills the chip anyway (throughput), sixteen when the
-// caller forces all 2000 iterations
+// launch is small (latency), one wave per pair when the launch fills the chip anyway (throughput); with the iteration
+// count forced, two waves of lane-per-hypothesis solvers (128 hypotheses per chunk)
 int waves_for(int nblocks, int force_max) {
-  if (force_max) return 16;
+  if (force_max) return 0;      // the LANES form
   return nblocks >= 512 ? 1 : 4;
 }
 
 }  // namespace
 
-#define EVH_LAUNCH_NW(nw, kernel, grid, stream, ...)                                                     \
-  do {                                                                                                  \
-    if ((nw) == 16) hipLaunchKernelGGL(kernel<16>, dim3(grid), dim3(16 * NL), 0, stream, __VA_ARGS__);   \
-    else if ((nw) == 4) hipLaunchKernelGGL(kernel<4>, dim3(grid), dim3(4 * NL), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kernel<1>, dim3(grid), dim3(NL), 0, stream, __VA_ARGS__);                    \
+#define EVH_LAUNCH_NW(nw, kernel, grid, stream, ...)                                                               \
+  do {                                                                                                            \
+    if ((nw) == 0) hipLaunchKernelGGL((kernel<2, true>), dim3(grid), dim3(2 * NL), 0, stream, __VA_ARGS__);        \
+    else if ((nw) == 4) hipLaunchKernelGGL((kernel<4, false>), dim3(grid), dim3(4 * NL), 0, stream, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((kernel<1, false>), dim3(grid), dim3(NL), 0, stream, __VA_ARGS__);                     \
   } while (0)
 
 int evh_launch_find_homography(evh_ctx* c, const EvhRansacArgs& A) {
@@ -1326,7 +1524,7 @@ int evh_launch_find_homography(evh_ctx* c, const EvhRansacArgs& A) {
 }
 int evh_launch_static_filter(evh_ctx* c, const double* d_H, const float* d_rows, int n, int* d_rbin, float* d_out,
                              int* d_count) {
-  hipLaunchKernelGGL(k_static_filter<4>, dim3(1), dim3(4 * NL), 0, c->stream, d_H, d_rows, n, d_rbin, d_out, d_count);
+  hipLaunchKernelGGL((k_static_filter<4, false>), dim3(1), dim3(4 * NL), 0, c->stream, d_H, d_rows, n, d_rbin, d_out, d_count);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
