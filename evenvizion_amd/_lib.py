@@ -38,6 +38,8 @@ SIGNATURES = {
     "evh_superposition_scan": (_i, [_vp, _vp, _i, _vp]),
     "evh_transform_points": (_i, [_vp, _vp, _i, _vp, _vp, _i, _d, _d, _i, _vp]),
     "evh_orb_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i]),
+    "evh_orb_detect_batch_resized": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i]),
+    "evh_stream_homography_batch_resized": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "evh_set_fast_lift": (_i, [_vp, _i]),
     "evh_set_fast_share": (_i, [_vp, _i]),
     "evh_set_fast_hint": (_i, [_vp, _i]),
@@ -215,11 +217,16 @@ class Context:
         return out
 
     # ---- K1..K6 ----
-    def orb_detect_batch(self, frames, nfeatures=500):
-        """frames: CUDA uint8 tensor [n,h,w] (gray) or [n,h,w,3] (BGR), contiguous."""
+    def orb_detect_batch(self, frames, nfeatures=500, resize_to=None):
+        """frames: CUDA uint8 tensor [n,h,w] (gray) or [n,h,w,3] (BGR), contiguous.  resize_to=(w, h): the frames are
+        shrunk to that working size inside the ingest kernel (imutils.resize fused into level 0)."""
         self._enter()
         n, h, w = frames.shape[:3]
         cn = 1 if frames.dim() == 3 else frames.shape[3]
+        if resize_to is not None and tuple(resize_to) != (w, h):
+            self._check(self.lib.evh_orb_detect_batch_resized(self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn,
+                                                              int(resize_to[0]), int(resize_to[1]), nfeatures))
+            return
         self._check(self.lib.evh_orb_detect_batch(self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures))
 
     def orb_detect_compute(self, frame, nfeatures=500):
@@ -307,11 +314,19 @@ class Context:
                                                        out_status.data_ptr()))
 
     def stream_homography_batch(self, frames, out_H, out_status, state_in=None, state_out=None, nfeatures=500, thr=3.0,
-                                max_iters=2000, conf=0.995, force_max_iters=False):
-        """frames: CUDA uint8 [n,h,w(,3)], n >= 2 consecutive frames of one stream -> n-1 pairs (stream semantics)."""
+                                max_iters=2000, conf=0.995, force_max_iters=False, resize_to=None):
+        """frames: CUDA uint8 [n,h,w(,3)], n >= 2 consecutive frames of one stream -> n-1 pairs (stream semantics).
+        resize_to=(w, h): full-size frames, the reference's resize_width fused into the ingest kernel."""
         self._enter()
         n, h, w = frames.shape[:3]
         cn = 1 if frames.dim() == 3 else frames.shape[3]
+        if resize_to is not None and tuple(resize_to) != (w, h):
+            self._check(self.lib.evh_stream_homography_batch_resized(
+                self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, int(resize_to[0]), int(resize_to[1]), nfeatures,
+                float(thr), int(max_iters), float(conf), int(bool(force_max_iters)),
+                state_in.data_ptr() if state_in is not None else None,
+                state_out.data_ptr() if state_out is not None else None, out_H.data_ptr(), out_status.data_ptr()))
+            return
         self._check(self.lib.evh_stream_homography_batch(
             self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, nfeatures, float(thr), int(max_iters), float(conf),
             int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,

@@ -278,7 +278,7 @@ void evh_destroy(evh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
-                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_area_tab, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -443,17 +443,37 @@ int evh_transform_points(evh_ctx* c, const double* h_M, int nmat, const int32_t*
   return rc;
 }
 
+static int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int sh, int w, int h, int channels,
+                        int64_t row_stride, int64_t frame_stride, int nfeatures);
+
 int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
                          int64_t row_stride, int64_t frame_stride, int nfeatures) {
+  return detect_batch(c, d_frames, nframes, w, h, w, h, channels, row_stride, frame_stride, nfeatures);
+}
+
+int evh_orb_detect_batch_resized(evh_ctx* c, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                                 int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures) {
+  return detect_batch(c, d_frames, nframes, src_w, src_h, w, h, channels, row_stride, frame_stride, nfeatures);
+}
+
+// (sw, sh): size of the frames handed over; (w, h): size ORB works on.  Different sizes = fused ingest (N2).
+static int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int sh, int w, int h, int channels,
+                        int64_t row_stride, int64_t frame_stride, int nfeatures) {
   if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, "evh_orb_detect_batch: NULL argument");
   const int share_group = c->fast_share ? c->fast_share_group : 0;   // set by the pair / stream entries for THIS call only
   c->fast_share_group = 0;
   if (nframes < 1 || nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "nframes exceeds max_frames");
   if (channels != 1 && channels != 3) return evh_fail(c, EVH_ERR_INVALID, "channels must be 1 or 3");
-  if (row_stride < (int64_t)w * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
+  if (row_stride < (int64_t)sw * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
+  if (sw < w || sh < h || sw < 1 || sh < 1) return evh_fail(c, EVH_ERR_UNSUPPORTED, "the working size must not exceed the frame size");
+  if (nframes > 65535 || h > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "too many frames / rows for one launch");
   int rc = configure(c, w, h, nfeatures);
   if (rc) return rc;
-  { EvhProfScope ps(c, EVH_ST_GRAY); rc = evh_launch_gray_level0(c, d_frames, nframes, channels, row_stride, frame_stride); }
+  {
+    EvhProfScope ps(c, EVH_ST_GRAY);
+    if (sw == w && sh == h) rc = evh_launch_gray_level0(c, d_frames, nframes, channels, row_stride, frame_stride);
+    else rc = evh_launch_ingest_level0(c, d_frames, nframes, sw, sh, channels, row_stride, frame_stride, w, h);
+  }
   if (rc) return rc;
   { EvhProfScope ps(c, EVH_ST_PYRAMID); rc = evh_launch_pyramid(c, nframes); }
   if (rc) return rc;
@@ -660,6 +680,24 @@ int evh_stream_homography_batch(evh_ctx* c, const uint8_t* d_frames, int nframes
   const int npairs = nframes - 1;
   c->fast_share_group = nframes;
   int rc = evh_orb_detect_batch(c, d_frames, nframes, w, h, channels, row_stride, frame_stride, nfeatures);
+  if (rc) return rc;
+  if ((rc = match_pairs(c, npairs, 1, 1, 0, 1))) return rc;
+  EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);
+  R.H = d_H; R.out_status = d_status;
+  if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
+  R.state_out = d_state_out;
+  return solve_pairs(c, R, npairs, 1, npairs, npairs);
+}
+
+int evh_stream_homography_batch_resized(evh_ctx* c, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                                        int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures,
+                                        double ransac_thr, int ransac_max_iters, double ransac_conf, int force_max_iters,
+                                        const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status) {
+  if (!c || !d_frames || !d_H || !d_status || nframes < 2) return evh_fail(c, EVH_ERR_INVALID, "evh_stream_homography_batch_resized: bad argument");
+  if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "chunk needs more frame slots than max_frames");
+  const int npairs = nframes - 1;
+  c->fast_share_group = nframes;
+  int rc = detect_batch(c, d_frames, nframes, src_w, src_h, w, h, channels, row_stride, frame_stride, nfeatures);
   if (rc) return rc;
   if ((rc = match_pairs(c, npairs, 1, 1, 0, 1))) return rc;
   EvhRansacArgs R = pair_ransac_args(c, ransac_thr, ransac_max_iters, ransac_conf, force_max_iters);

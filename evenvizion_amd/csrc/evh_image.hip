@@ -57,6 +57,65 @@ __global__ void k_resize_area_int(const uint8_t* __restrict__ src, int cn, int64
   dst[(int64_t)img * dst_img_stride + (int64_t)dy * dst_stride + e] = (uint8_t)min(max(v, 0), 255);
 }
 
+// N2: fused ingest.  The full-size frame is read ONCE: per output pixel the INTER_AREA sums of its channels
+// (same float32 tables and accumulation order as k_resize_area, rounded to uint8 per channel exactly as the resized
+// image would hold them), then cvtColor's gray weights on those bytes, written straight into pyramid level 0.  The
+// resized BGR image of video_processing.py:62,73 never exists in memory.
+__device__ __forceinline__ uint8_t gray_of(int b, int g, int r) { return (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14); }
+
+__global__ __launch_bounds__(256) void k_ingest_area(const uint8_t* __restrict__ src, int cn, int64_t src_stride,
+                                                     int64_t src_img_stride, uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes,
+                                                     int dw, int dh, int dst_stride, AreaTabDev T) {
+  const int img = blockIdx.z, dy = blockIdx.y;
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dx >= dw) return;
+  const uint8_t* S = src + (int64_t)img * src_img_stride;
+  const int x0 = T.xs[dx], xn = T.xcnt[dx], y0 = T.ys[dy], yn = T.ycnt[dy];
+  float sum[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < yn; j++) {
+    const uint8_t* row = S + (int64_t)T.ysi[y0 + j] * src_stride;
+    float buf[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < xn; k++) {
+      const uint8_t* px = row + (int64_t)T.xsi[x0 + k] * cn;
+      const float a = T.xal[x0 + k];
+#pragma unroll
+      for (int c = 0; c < 3; c++) if (c < cn) buf[c] = buf[c] + (float)px[c] * a;
+    }
+    const float beta = T.yal[y0 + j];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float term = beta * buf[c]; sum[c] = j == 0 ? term : sum[c] + term; }
+  }
+  int v[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) v[c] = min(max((int)rintf(sum[c]), 0), 255);
+  pyr[(int64_t)img * pyr_frame_bytes + (int64_t)dy * dst_stride + dx] = cn == 3 ? gray_of(v[0], v[1], v[2]) : (uint8_t)v[0];
+}
+
+__global__ __launch_bounds__(256) void k_ingest_area_int(const uint8_t* __restrict__ src, int cn, int64_t src_stride,
+                                                         int64_t src_img_stride, uint8_t* __restrict__ pyr,
+                                                         int64_t pyr_frame_bytes, int dw, int dh, int dst_stride, int isx,
+                                                         int isy) {
+  const int img = blockIdx.z, dy = blockIdx.y;
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dx >= dw) return;
+  const uint8_t* S = src + (int64_t)img * src_img_stride;
+  int sum[3] = {0, 0, 0};
+  for (int j = 0; j < isy; j++) {
+    const uint8_t* row = S + (int64_t)(dy * isy + j) * src_stride + (int64_t)dx * isx * cn;
+    for (int i = 0; i < isx; i++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) if (c < cn) sum[c] += row[i * cn + c];
+  }
+  int v[3];
+  const float scale = 1.f / (float)(isx * isy);
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int r = (isx == 2 && isy == 2) ? (sum[c] + 2) >> 2 : (int)rintf((float)sum[c] * scale);
+    v[c] = min(max(r, 0), 255);
+  }
+  pyr[(int64_t)img * pyr_frame_bytes + (int64_t)dy * dst_stride + dx] = cn == 3 ? gray_of(v[0], v[1], v[2]) : (uint8_t)v[0];
+}
+
 // N3: fixed-plane coordinate field of processing_visualization.py:407-408 -- every pixel (x, y) of
 // the resized frame mapped through the frame's superposed H -- and its maximum coordinate (the value
 // heatmap_video_processing returns and evenvizion_component.py writes to metrics_file.txt).
@@ -198,6 +257,65 @@ int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, i
   (void)hipStreamSynchronize(c->stream);  // the pageable upload and the table lifetime both end here
   (void)hipFree(d_blob);
   if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("k_resize_area: ") + hipGetErrorString(e));
+  return EVH_SUCCESS;
+}
+
+// INTER_AREA tables of one (source, destination) geometry, kept on the device by the context (a stream resizes
+// every chunk with the same geometry)
+static int area_tables(evh_ctx* c, int sw, int sh, int dw, int dh, double scale_x, double scale_y, AreaTabDev& T) {
+  const int64_t key = ((int64_t)sw << 48) ^ ((int64_t)sh << 32) ^ ((int64_t)dw << 16) ^ (int64_t)dh;
+  if (c->area_key != key || !c->d_area_tab) {
+    HostTab xt, yt;
+    build_area_tab(sw, dw, scale_x, xt);
+    build_area_tab(sh, dh, scale_y, yt);
+    std::vector<int> blob;
+    blob.insert(blob.end(), xt.start.begin(), xt.start.end());
+    blob.insert(blob.end(), xt.cnt.begin(), xt.cnt.end());
+    blob.insert(blob.end(), xt.si.begin(), xt.si.end());
+    for (float f : xt.al) { int v; std::memcpy(&v, &f, 4); blob.push_back(v); }
+    blob.insert(blob.end(), yt.start.begin(), yt.start.end());
+    blob.insert(blob.end(), yt.cnt.begin(), yt.cnt.end());
+    blob.insert(blob.end(), yt.si.begin(), yt.si.end());
+    for (float f : yt.al) { int v; std::memcpy(&v, &f, 4); blob.push_back(v); }
+    EVH_HIP(c, hipStreamSynchronize(c->stream));            // the previous tables may still be in use
+    if (c->d_area_tab) { (void)hipFree(c->d_area_tab); c->d_area_tab = nullptr; }
+    EVH_HIP(c, hipMalloc(&c->d_area_tab, blob.size() * sizeof(int)));
+    EVH_HIP(c, hipMemcpy(c->d_area_tab, blob.data(), blob.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->area_key = key; c->area_nx = (int)xt.si.size(); c->area_ny = (int)yt.si.size();
+  }
+  int* p = c->d_area_tab;
+  const size_t nx = (size_t)c->area_nx, ny = (size_t)c->area_ny;
+  T.xs = p; p += dw; T.xcnt = p; p += dw; T.xsi = p; p += nx; T.xal = reinterpret_cast<float*>(p); p += nx;
+  T.ys = p; p += dh; T.ycnt = p; p += dh; T.ysi = p; p += ny; T.yal = reinterpret_cast<float*>(p);
+  return EVH_SUCCESS;
+}
+
+// level 0 of every frame straight from the full-size source (k_ingest_area*); enlarging is outside the hot path
+int evh_launch_ingest_level0(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
+                             int64_t src_img_stride, int dw, int dh) {
+  const EvhLevel& L = c->g.lv[0];
+  const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+  {
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;      // the operator's own arithmetic
+    if (1. / inv_x < 1 || 1. / inv_y < 1) return evh_fail(c, EVH_ERR_UNSUPPORTED, "ingest: enlarging is outside the hot path");
+  }
+  const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+  (void)scale_x; (void)scale_y;
+  dim3 grid((dw + 255) / 256, dh, nimg);
+  const int isx = (int)std::lrint(sx), isy = (int)std::lrint(sy);
+  c->level1_fused = false;
+  if (std::fabs(sx - isx) < 2.220446049250313e-16 && std::fabs(sy - isy) < 2.220446049250313e-16) {
+    hipLaunchKernelGGL(k_ingest_area_int, grid, dim3(256), 0, c->stream, d_src, cn, src_stride, src_img_stride, c->d_pyr + L.off,
+                       c->g.pyr_frame_bytes, dw, dh, L.stride, isx, isy);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
+  AreaTabDev T;
+  int rc = area_tables(c, sw, sh, dw, dh, sx, sy, T);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_ingest_area, grid, dim3(256), 0, c->stream, d_src, cn, src_stride, src_img_stride, c->d_pyr + L.off,
+                     c->g.pyr_frame_bytes, dw, dh, L.stride, T);
+  EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }
 

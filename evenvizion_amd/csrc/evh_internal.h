@@ -68,6 +68,8 @@ struct evh_ctx {
   unsigned* d_fast_hist = nullptr;// [max_frames][8][256] sampled score histogram
   int* d_fast_hint = nullptr;     // [2][8] per-level threshold hint (ping-pong between detect calls) + [8][256] votes + [8] zeros
   int fast_hint_idx = 0;
+  int* d_area_tab = nullptr;      // INTER_AREA tables of the last ingest geometry (evh_launch_ingest_level0)
+  int64_t area_key = -1; int area_nx = 0, area_ny = 0;
   int* d_fast_redo = nullptr;     // [1 + max_frames*8] redo work list (count first)
   bool fast_lift = true;
   bool fast_share = true;         // evh_set_fast_share
@@ -116,6 +118,8 @@ int evh_fail(evh_ctx* ctx, int code, const std::string& msg);
 // ---- kernel launchers (each enqueues on ctx->stream) ----
 int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int channels, int64_t row_stride,
                            int64_t frame_stride);
+int evh_launch_ingest_level0(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
+                             int64_t src_img_stride, int dw, int dh);
 int evh_launch_pyramid(evh_ctx* c, int nframes);
 int evh_launch_fast(evh_ctx* c, int nframes, int share_group);
 int evh_launch_select(evh_ctx* c, int nframes);

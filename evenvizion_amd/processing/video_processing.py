@@ -3,7 +3,7 @@
 get_homography_dict keeps the reference signature and result layout
     {frame_no: {"H": 3x3 list}, ..., "resize_info": {"h", "w"}}       (first key is 2)
 but instead of one frame pair per Python iteration it reads the capture in chunks, uploads a chunk once, and runs
-the whole per-pair body on the GPU (evh_resize_area_u8 + evh_stream_homography_batch): ORB on every frame once
+the whole per-pair body on the GPU (evh_stream_homography_batch_resized: imutils.resize fused into the ingest kernel): ORB on every frame once
 (the reference recomputes each frame's features twice), matching / RANSAC #1 / static filter for all
 pairs of the chunk in parallel, and the final RANSAC as the sequential scan the running superposition requires
 (utils.py:351-358, video_processing.py:102-103).  Consecutive chunks overlap by one frame and carry
@@ -47,8 +47,6 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     # geometry), so a 4K source with resize_width=400 allocates 400-wide buffers
     ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures)
     dev = runtime.device()
-    shape_small = (chunk_frames, dh, dw) if cn == 1 else (chunk_frames, dh, dw, cn)
-    small = torch.empty(shape_small, dtype=torch.uint8, device=dev)
     H_dev = torch.empty(chunk_frames - 1, 9, dtype=torch.float64, device=dev)
     st_dev = torch.empty(chunk_frames - 1, dtype=torch.int32, device=dev)
     state = torch.zeros(18, dtype=torch.float64, device=dev)
@@ -69,9 +67,10 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
         if n < 2:
             break
         big = runtime.to_device(np.stack(pending))
-        ctx.resize_area(big, small[:n])                     # K0 (identity = copy)
-        ctx.stream_homography_batch(small[:n], H_dev, st_dev, state_in=state if have_state else None, state_out=state,
-                                    nfeatures=nfeatures)
+        # K0 fused into the ingest kernel: level 0 comes straight from the full-size frames (N2); equal sizes are the
+        # plain gray conversion
+        ctx.stream_homography_batch(big, H_dev, st_dev, state_in=state if have_state else None, state_out=state,
+                                    nfeatures=nfeatures, resize_to=(dw, dh))
         ctx.synchronize()
         Hs = H_dev[:n - 1].cpu().numpy().reshape(-1, 3, 3)
         sts = st_dev[:n - 1].cpu().numpy()

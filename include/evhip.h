@@ -133,6 +133,12 @@ int evh_set_fast_hint(evh_ctx* ctx, int on);
 /* number of keypoints of a frame slot, or <0 */
 int evh_orb_count(evh_ctx* ctx, int frame);
 /* capacity (rows) a caller must provide to evh_orb_download */
+/* N2, fused ingest: the same detect on frames of src_w x src_h that the reference would first shrink with
+ * imutils.resize(frame, width=w) (video_processing.py:62,73): level 0 is produced straight from the full-size frame
+ * (INTER_AREA per channel, rounded to uint8 as the resized image would be, then the gray weights) -- the resized BGR
+ * image is never materialised.  (w, h) is the working size: h = int(src_h * (w / float(src_w))).  Shrinking only.   */
+int evh_orb_detect_batch_resized(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                                 int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures);
 int evh_orb_capacity(const evh_ctx* ctx);
 /* copies one frame's features to HOST arrays (any pointer may be NULL): xy f32[n,2] (level-0 pixels, what
  * the reference keeps from kp.pt), desc u8[n,32], octave i32[n], lxy i32[n,2] (level coordinates),
@@ -192,6 +198,13 @@ int evh_stream_homography_batch(evh_ctx* ctx, const uint8_t* d_frames, int nfram
                                 int64_t row_stride, int64_t frame_stride, int nfeatures, double ransac_thr,
                                 int ransac_max_iters, double ransac_conf, int force_max_iters,
                                 const double* d_state_in, double* d_state_out, double* d_H, int32_t* d_status);
+/* The stream form on full-size frames with the reference's resize_width fused in (see evh_orb_detect_batch_resized):
+ * what get_homography_dict(capture, resize_width=w) runs per chunk.                                               */
+int evh_stream_homography_batch_resized(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int src_w, int src_h,
+                                        int channels, int64_t row_stride, int64_t frame_stride, int w, int h,
+                                        int nfeatures, double ransac_thr, int ransac_max_iters, double ransac_conf,
+                                        int force_max_iters, const double* d_state_in, double* d_state_out,
+                                        double* d_H, int32_t* d_status);
 /* Several independent streams in one batch: d_frames holds nstreams x frames_per_stream frames, stream-major
  * (all frames of stream 0, then stream 1, ...).  Everything up to the static filter runs over all frames / pairs
  * at once; the sequential scans of the streams then run concurrently, one wavefront per stream, each with its own

@@ -561,6 +561,47 @@ def test_resize_area(ctx):
         assert np.array_equal(out.cpu().numpy()[0], want)
 
 
+@pytest.mark.parametrize("cn", [3, 1])
+@pytest.mark.parametrize("sw,sh,width", [(1170, 658, 400), (1280, 720, 320)])
+def test_fused_ingest_equals_resize_then_detect(sw, sh, width, cn):
+    """N2: imutils.resize(frame, width) (INTER_AREA, video_processing.py:62,73) fused into the ingest kernel.  Level 0
+    (and level 1, key points, the whole stream) from the FULL-SIZE frames equal the oracle's resize -> gray -> ORB;
+    1170x658 -> 400x224 is the reference example's geometry (fractional scale: the float tables), 1280x720 -> 320x180
+    the integer-scale path."""
+    from evenvizion_amd._lib import Context
+    from evenvizion_amd.processing.video_processing import resized_shape
+    g, _ = S.make_stream(41, 4, sw, sh)
+    if cn == 3:      # three different channels, so that the gray weights matter
+        full = np.stack([g, np.roll(g, 7, axis=2), 255 - g], axis=-1)
+    else:
+        full = g
+    dw, dh = resized_shape(full.shape[1:], width)
+    small = [O.resize_area(f, dw, dh) for f in full]
+    gray = np.stack([O.bgr2gray(f) if cn == 3 else f for f in small])
+    c = Context(device=0, max_w=dw, max_h=dh, max_features=500, max_frames=len(full))
+    try:
+        c.orb_detect_batch(dev(full), resize_to=(dw, dh))
+        for f in range(len(full)):
+            assert np.array_equal(c.download_level(f, 0), gray[f])
+            assert np.array_equal(c.download_level(f, 1), O.orb_pyramid(gray[f])[1])
+        got, want = c.orb_download(1), O.orb_detect(gray[1])
+        for k in ("octave", "lx", "ly"):
+            assert np.array_equal(got[k], want[k])
+        assert np.array_equal(got["desc"], want["desc"])
+        n = len(full) - 1
+        H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch(dev(full), H, st, resize_to=(dw, dh))
+        c.synchronize()
+        Ho, so, rc = O.stream_gray(gray)
+        assert rc == -1 and np.array_equal(st.cpu().numpy(), so)
+        Hg = H.cpu().numpy().reshape(-1, 3, 3)
+        for p in range(n):
+            assert np.allclose(Hg[p], Ho[p], rtol=1e-9, atol=1e-12)
+    finally:
+        c.close()
+
+
 def test_single_frame_convenience_entries(ctx):
     """evh_orb_detect_compute / evh_resize_area_u8c3 (the single-image forms SURVEY 8b lists) == the batch entries."""
     a, _, _ = S.make_pair(77, 640, 360)
