@@ -80,6 +80,7 @@ def parse_args():
     ap.add_argument("--no-temporal", action="store_true", help="switch off the two exact shortcuts that lean on consecutive frames / calls looking alike (threshold sharing inside a pair, threshold hint across calls) for the MAIN timed loop")
     ap.add_argument("--force-max-iters", action="store_true", help="stream configs: evaluate all 2000 RANSAC samples (fixed-iteration stress variant)")
     ap.add_argument("--smooth", type=int, default=0, help="3x3 box-blur passes over the synthetic frames (content with fewer, weaker corners; informational)")
+    ap.add_argument("--skip-no-temporal", action="store_true", help="do not time the extra no-temporal loop (profiling runs: every launch of the run is then the same workload)")
     ap.add_argument("--gen-procs", type=int, default=0, help="host processes that generate the synthetic pairs (0 = auto; use 1 under rocprofv3: no child processes)")
     ap.add_argument("--contexts", type=int, default=1, help="independent contexts/streams the steps alternate over (pair configs)")
     args = ap.parse_args()
@@ -337,7 +338,7 @@ def main():
 
     # the same loop without the two content-dependent (exact) FAST shortcuts, reported next to the headline
     no_temporal_value = None
-    if not args.no_temporal and args.kind == "pairs":
+    if not args.no_temporal and args.kind == "pairs" and not args.skip_no_temporal:
         set_temporal(False)
         for _ in range(2):
             step()

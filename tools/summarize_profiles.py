@@ -75,12 +75,14 @@ if fast_bytes > 0:
 f = find("sq", "*counter_collection.csv")
 if f:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[short(r["Kernel_Name"])].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
     names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
              "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU"]
     with open(os.path.join(out, tag + "_pmc_sq.csv"), "w") as fo:
-        fo.write("# rocprofv3 --kernel-trace --pmc " + " ".join(names) + " : sums over 3 launches (1 warm-up + 2 steps) of 1024 pairs\n")
+        fo.write("# rocprofv3 --kernel-trace --pmc " + " ".join(names) + " : sums over the launches of the run (1 warm-up + 2 steps; python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --skip-no-temporal) of 1024 pairs\n")
         fo.write("# fractions are of SQ_WAVE_CYCLES (WAIT_ANY = parked on s_waitcnt/barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY = issuing)\n")
         fo.write("kernel,wave_cycles,wait_any,wait_inst_any,active_any,active_valu,active_lds,wait_inst_lds,insts_valu\n")
         for k, v in sorted(agg.items()):
@@ -93,7 +95,7 @@ if f:
 
     # VALU issue of the dominant (FAST) group per launch, for bench.py's informational "valu_issue" entry
     fast = [k for k in ("k_fast_sample", "k_fast_main", "k_fast_redo", "k_fast") if k in agg]
-    launches = 3.0
+    launches = float(max(len(disp.get("k_fast_main", ())), 1))
     insts = sum(agg[k]["SQ_INSTS_VALU"] for k in fast) / launches
     if insts > 0:
         json.dump({"fast@1280x720x1024_n500_c3": {"valu_wave_insts_per_launch": int(insts),
