@@ -216,6 +216,10 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   evh_ctx* c = new evh_ctx();
   c->device = device; c->max_w = max_w; c->max_h = max_h; c->max_features = max_features; c->max_frames = max_frames;
   c->kcap = kcap_for(max_features);
+  if ((size_t)c->kcap * 5 * sizeof(int) > 150 * 1024) {     // k_filter keeps five int lists of kcap entries in LDS
+    delete c;
+    return evh_fail(nullptr, EVH_ERR_CAPACITY, "evh_create: max_features too large for the matching filter's LDS lists (<= 6000)");
+  }
   int rc = EVH_SUCCESS;
   auto fail = [&](int code) { g_create_error = c->err; evh_destroy(c); return code; };
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }

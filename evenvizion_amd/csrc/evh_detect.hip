@@ -333,6 +333,19 @@ __device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const
   if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; S.scnt = 0; }
   const int stride8 = L.stride >> 3;
   const uint2* img8 = reinterpret_cast<const uint2*>(img);
+  if (y0 >= 4 && y0 + FT_H + 4 <= L.h && x0 >= 8 && x0 + FT_W + 8 <= L.stride) {   // workgroup-uniform: every staged byte exists
+    // item i = (row i / 18, 8-byte column i % 18); +256 items = +14 rows +4 columns
+    int r = (int)threadIdx.x / (FR_DW / 2), c8 = (int)threadIdx.x - r * (FR_DW / 2);
+    const uint2* p0 = img8 + mad24((uint32_t)(y0 - 4), (uint32_t)stride8, (uint32_t)((x0 - 8) >> 3));
+#pragma unroll
+    for (int j = 0; j < (FR_H * (FR_DW / 2) + 255) / 256; j++) {
+      if (j * 256 + (int)threadIdx.x < FR_H * (FR_DW / 2))
+        *reinterpret_cast<uint2*>(&S.raw[r * FR_DW + c8 * 2]) = p0[mad24((uint32_t)r, (uint32_t)stride8, (uint32_t)c8)];
+      r += 14; c8 += 4;
+      if (c8 >= FR_DW / 2) { c8 -= FR_DW / 2; r++; }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < FR_H * (FR_DW / 2); i += 256) {
     const int r = i / (FR_DW / 2), c8 = i - r * (FR_DW / 2);
     const int y = y0 - 4 + r, x = x0 - 8 + c8 * 8;
@@ -458,6 +471,8 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
   const int nq = S.qcnt;
   const uint8_t* rawb = reinterpret_cast<const uint8_t*>(S.raw);
   uint8_t* scoreb = reinterpret_cast<uint8_t*>(S.score);
+  // four lanes per queued quad.  (A pixel-granular list -- fewer busy waves -- was measured at +1.0 ms: the four
+  // lanes of a quad read neighbouring bytes of the same LDS words, scattered pixels conflict on the banks.)
   for (int e = threadIdx.x; e < nq * 4; e += 256) {
     const uint32_t ent = S.lst[e >> 2];
     const int j = e & 3;

@@ -7,7 +7,7 @@ set -e
 for rep in 1 2; do
   for v in a b; do
     if [ $v = a ]; then export EVHIP_LIBRARY=$PWD/tools/ab/a.so; else unset EVHIP_LIBRARY; fi
-    python bench.py --steps 10 --warmup 2 2>/dev/null | python -c "
+    python bench.py --steps 10 --warmup 2 --cpu-pairs 0 --skip-no-temporal 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stage_ms']
 print('$v', d['value'], d['ms_per_step'], {k: round(x,2) for k,x in s.items()})"
