@@ -137,8 +137,16 @@ int dalloc(evh_ctx* c, T** p, size_t n) {
   return EVH_SUCCESS;
 }
 
+// fixed-iteration mode keeps the per-lane eigenvector matrices of its hypotheses in a global scratch (one block per
+// workgroup = per pair slot); allocated on first use
+int ensure_lane_scratch(evh_ctx* c) {
+  if (c->d_lane_v) return EVH_SUCCESS;
+  return dalloc(c, &c->d_lane_v, (size_t)c->max_frames * EVH_LANE_V_DOUBLES);
+}
+
 EvhRansacArgs pair_ransac_args(evh_ctx* c, double thr, int max_iters, double conf, int force_max) {
   EvhRansacArgs R{};
+  if (force_max && ensure_lane_scratch(c) == EVH_SUCCESS) R.lane_v = c->d_lane_v;
   R.pts = c->d_pts; R.pts2 = c->d_pts2; R.row_stride = c->kcap; R.npts = c->d_npts; R.npts2 = c->d_npts2;
   R.status = c->d_pstatus; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = force_max;
   R.mask = c->d_mask; R.crow = c->d_crow; R.lm = c->d_lm; R.H1 = c->d_H1; R.info = c->d_info;
@@ -282,7 +290,7 @@ void evh_destroy(evh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
-                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_area_tab, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -618,6 +626,7 @@ static int find_homography_entry(evh_ctx* c, const float* d_pts, int n, double t
   // scratch: the per-pair buffers viewed as one big problem
   EvhRansacArgs R{};
   R.pts = const_cast<float*>(d_pts); R.n_fixed = n; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = force_max;
+  if (force_max) { int lr = ensure_lane_scratch(c); if (lr) return lr; R.lane_v = c->d_lane_v; }
   R.mask = c->d_mask; R.crow = c->d_crow; R.lm = c->d_lm;
   R.H = c->d_small; R.found = reinterpret_cast<int*>(c->d_small + 16); R.info = reinterpret_cast<int*>(c->d_small + 17);
   int rc = evh_launch_find_homography(c, R);

@@ -24,10 +24,12 @@ struct EvhRansacArgs {
   double* H;             // final H per pair
   int* out_status;       // final status per pair
   int* found;            // single-problem entry
+  double* lane_v;        // fixed-iteration mode: global scratch for the per-lane eigenvector matrices, [workgroup][4][81][64] f64
   unsigned long long* prof;  // optional cycle accounting (debug, EVH_RANSAC_PROF); NULL normally
   int* info;             // [pair][8] (may be NULL): ransac iters, best inliers, LM iters for RANSAC #1 (+0) and #2 (+4)
 };
 
+#define EVH_LANE_V_DOUBLES (4 * 81 * 64)   // per workgroup
 struct evh_ctx;
 int evh_launch_find_homography(evh_ctx* c, const EvhRansacArgs& A);
 int evh_launch_static_filter(evh_ctx* c, const double* d_H, const float* d_rows, int n, int* d_rbin, float* d_out,

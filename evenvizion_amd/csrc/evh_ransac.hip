@@ -495,26 +495,29 @@ __device__ __forceinline__ bool dlt4_rows(RowMat& M, int lane, bool valid, const
 
 
 // ---- one 9x9 eigen-problem PER LANE (fixed-iteration RANSAC: thousands of hypotheses, throughput matters, latency does
-// not): the serial algorithm as it stands, 64 problems side by side.  Every lane's matrices live in LDS as
-// [element][lane] (512 bytes between elements: whatever element a lane picks, it stays on its own banks).
-// Elements: 0..35 upper off-diagonal of A (row i starts at i(17-i)/2), 36..44 W, 45..125 V (rows).  indR / indC are
+// not): the serial algorithm as it stands, 64 problems side by side.  A and W of every lane live in LDS as
+// [element][lane] (512 bytes between elements: whatever element a lane picks, it stays on its own banks): 0..35 upper
+// off-diagonal of A (row i starts at i(17-i)/2), 36..44 W.  V (81 elements per lane, written and read only by its own
+// lane, never on the pivot's critical path) lives in a global scratch of the same [element][lane] shape -- it stays in
+// L2 -- so that four waves fit a compute unit instead of two; its loads are issued before the rotation scalars.  indR / indC are
 // one register per index.  The rescans of indR / indC for the two rotated indices run inside the
 // rotation loop on the freshly rotated values (ascending index, strict '<': the first maximum, as the reference).
-#define LM_ELEMS 126
+#define LM_ELEMS 45
 #define LM_W 36
-#define LM_V 45
+#define LV_ELEMS 81
 __device__ __forceinline__ int lm_arow(int i) { return (i * (17 - i)) >> 1; }          // first element of row i (j = i+1)
 __device__ __forceinline__ int lm_a(int i, int j) { return lm_arow(i) + j - i - 1; }     // i < j
 // L = this lane's column: element e at L[e * 64].  A (upper) and W (diagonal) hold the input.  Returns the row of V
 // that belongs to the smallest eigenvalue under the reference's selection sort.
-__device__ __forceinline__ int jacobi_lanes9(double* L, bool active) {
+__device__ __forceinline__ int jacobi_lanes9(double* L, double* Vg, bool active) {
   const int N = 9;
 #define EL(e) L[(e) * NL]
+#define VL(e) Vg[(e) * NL]
   if (active) {
 #pragma unroll
     for (int i = 0; i < N; i++)
 #pragma unroll
-      for (int j = 0; j < N; j++) EL(LM_V + i * N + j) = i == j ? 1.0 : 0.0;
+      for (int j = 0; j < N; j++) VL(i * N + j) = i == j ? 1.0 : 0.0;
   }
   int indR[9], indC[9];                // one register each (static index in every loop below)
 #pragma unroll
@@ -541,7 +544,7 @@ __device__ __forceinline__ int jacobi_lanes9(double* L, bool active) {
   unsigned amax = 0;
   if (active) {
 #pragma unroll
-    for (int e = 0; e < LM_V; e++) amax = max(amax, hi32(EL(e)) & 0x7FFFFFFFu);
+    for (int e = 0; e < LM_ELEMS; e++) amax = max(amax, hi32(EL(e)) & 0x7FFFFFFFu);
   }
   const bool plain = __ballot(active && amax >= 0x52B00000u) != 0ull;
   bool act = active;
@@ -578,7 +581,7 @@ __device__ __forceinline__ int jacobi_lanes9(double* L, bool active) {
       e1[i] = rot ? (i < k ? lm_arow(i) + k - i - 1 : rowk + i - k - 1) : 0;
       e2[i] = rot ? (i < l ? lm_arow(i) + l - i - 1 : rowl + i - l - 1) : 0;
       a0[i] = EL(e1[i]); b0[i] = EL(e2[i]);
-      va[i] = EL(LM_V + k * N + i); vb[i] = EL(LM_V + l * N + i);
+      va[i] = VL(k * N + i); vb[i] = VL(l * N + i);
     }
     const double wk = EL(LM_W + k), wl = EL(LM_W + l);
     double c = 1, sn = 0, t = 0;
@@ -605,8 +608,8 @@ __device__ __forceinline__ int jacobi_lanes9(double* L, bool active) {
       EL(LM_W + k) = wk - t; EL(LM_W + l) = wl + t;
 #pragma unroll
       for (int i = 0; i < N; i++) {
-        EL(LM_V + k * N + i) = va[i] * c - vb[i] * sn;
-        EL(LM_V + l * N + i) = va[i] * sn + vb[i] * c;
+        VL(k * N + i) = va[i] * c - vb[i] * sn;
+        VL(l * N + i) = va[i] * sn + vb[i] * c;
       }
     }
     // indR / indC of the two rotated indices (row N-1 has no indR, column 0 no indC: those registers are never read)
@@ -631,10 +634,11 @@ __device__ __forceinline__ int jacobi_lanes9(double* L, bool active) {
   }
   return pm[N - 1];
 #undef EL
+#undef VL
 }
 
 // normalised DLT of this LANE's own 4 correspondences (M -> m); returns whether a model was produced
-__device__ __forceinline__ bool dlt4_lane(double* L, bool valid, const float* Mx, const float* My, const float* mx,
+__device__ __forceinline__ bool dlt4_lane(double* L, double* Vg, bool valid, const float* Mx, const float* My, const float* mx,
                                           const float* my, double* H) {
   double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
 #pragma unroll
@@ -664,11 +668,11 @@ __device__ __forceinline__ bool dlt4_lane(double* L, bool valid, const float* Mx
         L[(j == k ? LM_W + j : lm_a(j, k)) * NL] = acc;
       }
   }
-  const int r8 = jacobi_lanes9(L, ok);
+  const int r8 = jacobi_lanes9(L, Vg, ok);
   if (ok) {
     double H0[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) H0[i] = L[(LM_V + r8 * 9 + i) * NL];
+    for (int i = 0; i < 9; i++) H0[i] = Vg[(r8 * 9 + i) * NL];
     dlt_finish_from(H0, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
   }
   return ok;
@@ -1083,7 +1087,7 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
 }
 
 // LANES: the hypothesis phase gives every LANE its own hypothesis (jacobi_lanes9) instead of every 16-lane row -- the
-// fixed-iteration mode, where thousands of hypotheses are evaluated and throughput counts; 63 KB of LDS per wave.
+// fixed-iteration mode, where thousands of hypotheses are evaluated and throughput counts; 23 KB of LDS per wave.
 template <int NW, bool LANES>
 struct BlockLds {
   RowMat m[LANES ? 1 : NW][NG];
@@ -1103,7 +1107,8 @@ struct BlockLds {
 // compacted inliers.  Ends with a workgroup barrier.
 template <int NW, bool LANES>
 __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, const float* rows, int n, double thr, int maxItersArg, double conf,
-                                      int force_max, uint8_t* mask, float* crow, int* info, unsigned long long* prof) {
+                                      int force_max, uint8_t* mask, float* crow, int* info, unsigned long long* prof,
+                                      double* lane_v /* LANES: this workgroup's NW * 81 * 64 doubles of global scratch */) {
   const unsigned long long pf0 = pf_now();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15;
   SolveLds& S = B.s;
@@ -1123,7 +1128,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
     return S.ib[2] != 0;
   }
   const float t = (float)(thr * thr);
-  const int HC = LANES ? NW * NL : NW * NG;                 // hypotheses per chunk
+  constexpr int HC = LANES ? NW * NL : NW * NG;             // hypotheses per chunk
   const int myh = LANES ? wave * NL + lane : wave * NG + row;
   Rng rng;
   const FastMod fm((unsigned)n);
@@ -1153,7 +1158,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
     const unsigned long long ps0 = pf_now();
     pf_add(prof, PF_RNG, ps0 - pr0);
     bool ok;
-    if constexpr (LANES) ok = dlt4_lane(B.u.lmat + (wave * LM_ELEMS * NL + lane), valid, Mx, My, mx, my_, H);
+    if constexpr (LANES) ok = dlt4_lane(B.u.lmat + (wave * LM_ELEMS * NL + lane), lane_v + (wave * LV_ELEMS * NL + lane), valid, Mx, My, mx, my_, H);
     else ok = dlt4_rows(B.m[wave][row], lane, valid, Mx, My, mx, my_, H);
     const unsigned long long ps1 = pf_now();
     pf_add(prof, PF_SETUP, ps1 - ps0);
@@ -1189,10 +1194,18 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
     __syncthreads();
     const unsigned long long ps3 = pf_now();
     pf_add(prof, PF_BARRIER, ps3 - ps2);
-    // sequential replay in sample order (every thread, identically)
+    // sequential replay in sample order (every thread, identically); the chunk's entries are fetched once into
+    // registers (lane j holds entries j, j + 64, ...) and walked with v_readlane instead of one LDS round trip each
+    constexpr int NSEG = (HC + NL - 1) / NL;
+    unsigned er[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; sg++) er[sg] = sg * NL + lane < HC ? (unsigned)hyp[sg * NL + lane] : 0u;
     int best_h = -1;
-    for (int h = 0; h < HC; h++) {
-      const unsigned e = (unsigned)hyp[h];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; sg++)
+    for (int hj = 0; hj < (HC - sg * NL < NL ? HC - sg * NL : NL) && !stop; hj++) {
+      const int h = sg * NL + hj;
+      const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)er[sg], hj);
       if (!(e >> 31)) {  // rejected sample: counts towards the 10000-attempt bound of one draw
         if (++run >= 10000) { stop = true; break; }
         continue;
@@ -1361,7 +1374,7 @@ __device__ __forceinline__ int compute_homography_block(BlockLds<NW, LANES>& B, 
     __syncthreads();
     use = trow;
   }
-  const bool found = find_homography_block<NW, LANES>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
+  const bool found = find_homography_block<NW, LANES>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof, A.lane_v ? A.lane_v + (int64_t)blockIdx.x * (NW * LV_ELEMS * NL) : nullptr);
   if (wave == 0) {
     int s = 0;
     for (int i = lane; i < n; i += NL) s += mask[i];
@@ -1386,7 +1399,7 @@ __global__ __launch_bounds__(NW * NL) void k_find_homography(EvhRansacArgs A) {
   BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
   const int tid = threadIdx.x;
   const int n = A.n_fixed;
-  const bool found = find_homography_block<NW, LANES>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info, A.prof);
+  const bool found = find_homography_block<NW, LANES>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info, A.prof, A.lane_v);
   if (tid < 9) A.H[tid] = found ? B.s.H[tid] : 0.0;
   if (tid == 0) A.found[0] = found ? 1 : 0;
 }
@@ -1416,7 +1429,7 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_static(EvhRansacArgs A) {
   float* crow = A.crow + (int64_t)p * A.row_stride * 4;
   int* rbin = reinterpret_cast<int*>(A.lm + (int64_t)p * A.row_stride * 4);
   int* info = A.info ? A.info + 8 * p : nullptr;
-  const bool found = find_homography_block<NW, LANES>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof);
+  const bool found = find_homography_block<NW, LANES>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof, A.lane_v ? A.lane_v + (int64_t)blockIdx.x * (NW * LV_ELEMS * NL) : nullptr);
   if (!found) {
     if (tid == 0) { A.status[p] = EVH_PAIR_NO_PROVISIONAL_H; A.npts2[p] = 0; }
     return;
@@ -1502,7 +1515,7 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A
 
 // waves per workgroup: enough rows to cover the handful of hypotheses an adaptive RANSAC needs in one chunk when the
 // launch is small (latency), one wave per pair when the launch fills the chip anyway (throughput); with the iteration
-// count forced, two waves of lane-per-hypothesis solvers (128 hypotheses per chunk)
+// count forced, four waves of lane-per-hypothesis solvers (256 hypotheses per chunk)
 int waves_for(int nblocks, int force_max) {
   if (force_max) return 0;      // the LANES form
   return nblocks >= 512 ? 1 : 4;
@@ -1512,12 +1525,13 @@ int waves_for(int nblocks, int force_max) {
 
 #define EVH_LAUNCH_NW(nw, kernel, grid, stream, ...)                                                               \
   do {                                                                                                            \
-    if ((nw) == 0) hipLaunchKernelGGL((kernel<2, true>), dim3(grid), dim3(2 * NL), 0, stream, __VA_ARGS__);        \
+    if ((nw) == 0) hipLaunchKernelGGL((kernel<4, true>), dim3(grid), dim3(4 * NL), 0, stream, __VA_ARGS__);        \
     else if ((nw) == 4) hipLaunchKernelGGL((kernel<4, false>), dim3(grid), dim3(4 * NL), 0, stream, __VA_ARGS__);  \
     else hipLaunchKernelGGL((kernel<1, false>), dim3(grid), dim3(NL), 0, stream, __VA_ARGS__);                     \
   } while (0)
 
 int evh_launch_find_homography(evh_ctx* c, const EvhRansacArgs& A) {
+  if (A.force_max && !A.lane_v) return evh_fail(c, EVH_ERR_HIP, "fixed-iteration RANSAC: the per-lane scratch could not be allocated");
   EVH_LAUNCH_NW(waves_for(1, A.force_max), k_find_homography, 1, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
@@ -1530,6 +1544,7 @@ int evh_launch_static_filter(evh_ctx* c, const double* d_H, const float* d_rows,
 }
 int evh_launch_ransac_static(evh_ctx* c, const EvhRansacArgs& A, int npairs) {
   if (npairs <= 0) return EVH_SUCCESS;
+  if (A.force_max && !A.lane_v) return evh_fail(c, EVH_ERR_HIP, "fixed-iteration RANSAC: the per-lane scratch could not be allocated");
   EVH_LAUNCH_NW(waves_for(npairs, A.force_max), k_ransac_static, npairs, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
@@ -1537,6 +1552,7 @@ int evh_launch_ransac_static(evh_ctx* c, const EvhRansacArgs& A, int npairs) {
 int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A_, int npairs, int nstreams, int pitch) {
   if (npairs <= 0) return EVH_SUCCESS;
   EvhRansacArgs A = A_;
+  if (A.force_max && !A.lane_v) return evh_fail(c, EVH_ERR_HIP, "fixed-iteration RANSAC: the per-lane scratch could not be allocated");
   static const bool want_prof = getenv("EVH_RANSAC_PROF") != nullptr;   // debugging aid: cycle accounting to stderr
   unsigned long long* d_prof = nullptr;
   if (want_prof) {
