@@ -379,6 +379,12 @@ def main():
             roofline["valu_issue"] = {"wave_insts_per_launch": entry["valu_wave_insts_per_launch"],
                                       "per_clk_per_cu_at_2.4GHz": round(per, 3), "ceiling": [0.96, 1.75],
                                       "valu_source": "replayed: profiles/%s[%s] (%s); duration measured in this run" % (fname, key, entry.get("source", ""))}
+    if dom == "fast":
+        # the FAST tile grid covers only the pixels ORB can emit (31-px border rule) plus one ring: the kernel reads this
+        # fraction of the P*A bytes the SURVEY 8d model charges it with (`achieved` keeps the model's bytes)
+        lvs = level_sizes(w, h)
+        roofline["fast_tiled_fraction"] = round(sum(max(1, -(-(a - 55) // 128)) * 128 * max(1, -(-(b - 62) // 28)) * 28 for a, b in lvs)
+                                                / float(sum(a * b for a, b in lvs)), 4)
     # whole-pipeline view: independent pair = 2*B_frame + B_match + B_out; a stream pair = 1 frame
     pipe_bytes = (2 if args.kind == "pairs" else 1) * sum(per_frame.values()) + sum(per_pair.values())
     roofline["pipeline_bytes_per_pair"] = int(pipe_bytes)

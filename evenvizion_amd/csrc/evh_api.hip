@@ -56,7 +56,10 @@ void compute_geometry(int w, int h, int nfeatures, EvhGeom& g) {
     L.cand_cap = (L.w / 2 + 1) * (L.h / 2 + 1) + 64;  // NMS admits at most one corner per 2x2 block
     L.cand_off = coff;
     coff += L.cand_cap;
-    L.tiles_x = (L.w + 127) / 128; L.tiles_y = (L.h + 27) / 28;  // k_fast tile: 128 x 28
+    // k_fast tiles (128 x 28) cover only what can be emitted: ORB drops corners within 31 px of the border
+    // (runByImageBorder), so the tile grid starts at (EVH_FAST_OX, EVH_FAST_OY) = (24, 31) and ends at w-32 / h-32;
+    // the one ring of neighbours NMS needs comes from the tiles' halo
+    L.tiles_x = std::max(1, (L.w - 31 - EVH_FAST_OX + 127) / 128); L.tiles_y = std::max(1, (L.h - 31 - EVH_FAST_OY + 27) / 28);
     L.tile_start = tiles;
     tiles += L.tiles_x * L.tiles_y;
     L.tab_off = tab;

@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
   const int l = fast_level_of_tile(A, t);
   const EvhLevel L = A.lv[l];
   const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-  const int x0 = tx * FT_W, y0 = ty * FT_H;
+  const int x0 = EVH_FAST_OX + tx * FT_W, y0 = EVH_FAST_OY + ty * FT_H;
   fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
   __syncthreads();
   fast_dense_scores(S, L, x0, y0);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_sample(FastArgs A) {
   const int t = (f * 5 + l) % mod + s * mod;          // sampled tile index inside the level
   if (t >= L.tiles_x * L.tiles_y) return;
   const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-  const int x0 = tx * FT_W, y0 = ty * FT_H;
+  const int x0 = EVH_FAST_OX + tx * FT_W, y0 = EVH_FAST_OY + ty * FT_H;
   const int hint = A.hint_in[l];
   const int Tp = (hint > 36 && hint < 256) ? max(EVH_FAST_THR + 1, (hint * 7) >> 3) : 0;   // 0: dense sample
   fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_main(FastArgs A) {
   const int l = fast_level_of_tile(A, t);
   const EvhLevel L = A.lv[l];
   const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-  const int x0 = tx * FT_W, y0 = ty * FT_H;
+  const int x0 = EVH_FAST_OX + tx * FT_W, y0 = EVH_FAST_OY + ty * FT_H;
   const int T = A.thr[f * EVH_NLEVELS + l];
   fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
   __syncthreads();
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void k_fast_redo(FastArgs A) {
     const int t = blockIdx.x;
     if (t < L.tiles_x * L.tiles_y) {
       const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
-      const int x0 = tx * FT_W, y0 = ty * FT_H;
+      const int x0 = EVH_FAST_OX + tx * FT_W, y0 = EVH_FAST_OY + ty * FT_H;
       fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
       __syncthreads();
       fast_dense_scores(S, L, x0, y0);

@@ -10,6 +10,8 @@
 #define EVH_NLEVELS 8
 #define EVH_EDGE 31          // ORB edgeThreshold
 #define EVH_FAST_THR 20      // ORB fastThreshold
+#define EVH_FAST_OX 24       // origin of the FAST tile grid (multiple of 8: the staging loads are 8-byte aligned)
+#define EVH_FAST_OY 31
 #define EVH_K1CAP 4096       // stage-1 (FAST-score) survivors per level held in LDS
 #define EVH_K2CAP 1280       // stage-2 (Harris) survivors per level held in LDS
 

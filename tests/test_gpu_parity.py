@@ -103,10 +103,11 @@ def test_fast_threshold_lifting_is_exact(ctx):
     frames = []
     for f in range(2):
         img = np.full((720, 1280), 120, np.uint8)
-        for t in range(260):                          # level 0 = 10 x 26 tiles of 128 x 28
+        for t in range(240):                          # level 0 = 10 x 24 tiles of 128 x 28, grid origin (24, 31)
             if t % 27 == (f * 5) % 27:                # k_fast_sample's lattice for level 0 (every 27th tile)
                 ty, tx = divmod(t, 10)
-                img[ty * 28:(ty + 1) * 28, tx * 128:(tx + 1) * 128] = tex[ty * 28:(ty + 1) * 28, tx * 128:(tx + 1) * 128]
+                ys, xs = slice(31 + ty * 28, 31 + (ty + 1) * 28), slice(24 + tx * 128, 24 + (tx + 1) * 128)
+                img[ys, xs] = tex[ys, xs]
         frames.append(img)
     frames.append(tex)
     rng = np.random.default_rng(8)
