@@ -1,4 +1,4 @@
-// evh_ransac.h -- argument block of the homography kernels (one wavefront per frame pair).
+// evh_ransac.h -- argument block of the homography kernels (one workgroup of 1 or 4 wavefronts per frame pair / stream).
 #pragma once
 #include <stdint.h>
 

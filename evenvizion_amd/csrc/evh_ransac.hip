@@ -5,17 +5,24 @@
 // (utils.py:118-145).
 //
 // Shape of the computation.  One workgroup of NW wavefronts per frame pair (or per stream in the sequential scan).
-// * RANSAC hypotheses are evaluated 4*NW at a time: every 16-lane row of every wave owns one 4-point hypothesis.  The
-//   sample sequence of the fixed-seed multiply-with-carry generator is advanced by every lane identically, each row
-//   keeps its own quadruple, solves its normalised DLT (9x9 Jacobi eigen-solver, f64) and counts its inliers; a
-//   sequential replay in sample order then applies "strictly more inliers wins" and the adaptive iteration bound
-//   exactly like a serial RANSAC (over-evaluated hypotheses are simply ignored).
-// * The eigen-solver (jacobi_rows) is the latency-critical piece: measured on this part a dependent f64 divide costs
-//   69 cycles, a square root 106, an LDS round trip 65-125 and one wave issues one instruction per ~5 cycles, so the
-//   solver is written to a budget of instructions per rotation: pivot search and the four index rescans are DPP
-//   reductions on the raw bits of |a_ij| (one v_max_u32_dpp per step), the rotated values never leave registers
-//   before they are rescanned, and the c/s/t scalars use the exact divide / square-root sequences without the range
-//   scaling they cannot need here (bit-identical results, a slow path covers out-of-range operands).
+// * RANSAC hypotheses are evaluated a chunk at a time: every 16-lane row of every wave owns one 4-point hypothesis
+//   (4 * NW per chunk), or -- when the caller forces the iteration count -- every LANE does (64 * NW per chunk).  The
+//   sample sequence of the fixed-seed multiply-with-carry generator is advanced by every lane identically (scalar
+//   code), each owner keeps its own quadruple, solves its normalised DLT (9x9 Jacobi eigen-solver, f64) and counts its
+//   inliers; a sequential replay in sample order then applies "strictly more inliers wins" and the adaptive iteration
+//   bound exactly like a serial RANSAC (over-evaluated hypotheses are simply ignored).
+// * The eigen-solver is the latency-critical piece: measured on this part (tools/ubench/lat.hip) a dependent f64 divide
+//   costs 69 cycles, a square root 106, an LDS round trip 65-125 and a lone wave issues one instruction per ~5 cycles.
+//   Three forms of the same arithmetic (same pivot order, bit-identical results):
+//     jacobi_rows  -- one matrix per 16-lane row, four per wave (hypothesis chunks): pivot candidates in registers,
+//                     pivot search and the four index rescans as DPP integer reductions on the raw bits of |a_ij|,
+//                     rotated values rescanned before they leave registers;
+//     jacobi_one   -- one matrix for the whole wave (refit, LM solves): pivot through SGPRs, W in registers, the two
+//                     rescans side by side, results exchanged by v_permlane16_swap;
+//     jacobi_lanes9 -- one matrix per lane (fixed-iteration mode): the serial algorithm, A and W in LDS as
+//                     [element][lane], V in an L2-resident global scratch.
+//   The c/s/t scalars of a rotation use the exact divide / square-root instruction sequences without the range
+//   scaling they cannot need here (one check per solve; out-of-range input takes a plain-arithmetic sweep).
 // * Sums over points (centroids, L^T L, J^T J, J^T r, residual norms) keep the serial summation order of the operator
 //   being replaced: the points go through a 64-point LDS tile (all lanes compute their own point's terms), then one
 //   lane per output entry adds the tile's terms in point order.
