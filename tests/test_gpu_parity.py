@@ -549,6 +549,34 @@ def test_multi_stream_batch_equals_each_stream_alone():
         c.close()
 
 
+def test_fixed_iterations_in_every_batch_form():
+    """force_max_iters through the other entry points (the per-lane solver in k_ransac_static / _final_pairs /
+    _final_stream with several workgroups): independent pairs == the first pair of a two-frame stream, several streams
+    at once == each stream alone; the single stream itself is checked against the oracle in
+    test_config2_stream_720p_2000kp."""
+    from evenvizion_amd._lib import Context
+    w, h = 400, 224
+    streams = [S.make_stream(60 + i, 4, w, h)[0] for i in range(2)]
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=8)
+    try:
+        ref = []
+        for fr in streams:
+            H = torch.zeros(3, 9, dtype=torch.float64, device="cuda"); st = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+            c.stream_homography_batch(dev(fr), H, st, force_max_iters=True); c.synchronize()
+            ref.append((H.clone(), st.clone()))
+        Hm = torch.zeros(2, 3, 9, dtype=torch.float64, device="cuda"); sm = torch.full((2, 3), -1, dtype=torch.int32, device="cuda")
+        c.multi_stream_homography_batch(dev(np.stack(streams)), Hm, sm, force_max_iters=True); c.synchronize()
+        for i in range(2):
+            assert torch.equal(sm[i], ref[i][1]) and torch.equal(Hm[i], ref[i][0])
+        pairs = np.stack([streams[0][0], streams[0][1], streams[1][0], streams[1][1]])     # (prev0, cur0, prev1, cur1)
+        Hp = torch.zeros(2, 9, dtype=torch.float64, device="cuda"); sp = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(pairs), 2, 0, Hp, sp, force_max_iters=True); c.synchronize()
+        for i in range(2):
+            assert int(sp[i]) == int(ref[i][1][0]) == 0 and torch.equal(Hp[i], ref[i][0][0])
+    finally:
+        c.close()
+
+
 def test_resize_area(ctx):
     rng = np.random.default_rng(4)
     for (sw, sh, width, cn) in [(1170, 658, 400, 3), (1280, 720, 320, 3), (800, 600, 400, 1), (900, 300, 300, 3),
