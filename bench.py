@@ -82,6 +82,8 @@ def parse_args():
     ap.add_argument("--smooth", type=int, default=0, help="3x3 box-blur passes over the synthetic frames (content with fewer, weaker corners; informational)")
     ap.add_argument("--skip-no-temporal", action="store_true", help="do not time the extra no-temporal loop (profiling runs: every launch of the run is then the same workload)")
     ap.add_argument("--gen-procs", type=int, default=0, help="host processes that generate the synthetic pairs (0 = auto; use 1 under rocprofv3: no child processes)")
+    ap.add_argument("--sync-solve", action="store_true",
+                    help="diagnostic: RANSAC on the detect stream (no overlap with the next step), for clean per-stage times")
     ap.add_argument("--contexts", type=int, default=1, help="independent contexts/streams the steps alternate over (pair configs)")
     args = ap.parse_args()
     cfg = {1: dict(kind="pairs", w=1280, h=720, nfeat=500, pairs=1024, steps=10),
@@ -202,7 +204,7 @@ def main():
         # The RANSAC kernels of a step run on the context's solve stream and overlap the next step's detect kernels;
         # results are double-buffered so that a step never overwrites what the previous step's gather still reads.
         for c_ in ctxs:
-            c_.set_async_solve(True)
+            c_.set_async_solve(not args.sync_solve)
         NBUF = 2 * NCTX
         Hs = [torch.zeros(B, 9, dtype=torch.float64, device=dev) for _ in range(NBUF)]
         sts = [torch.full((B,), -1, dtype=torch.int32, device=dev) for _ in range(NBUF)]
@@ -456,7 +458,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "bench_config": args.config,
                        "pairs_per_step_per_gpu": B, "unique_pairs": U if args.kind == "pairs" else None,
-                       "parallelism": par, "contexts_per_gpu": NCTX,
+                       "parallelism": par, "contexts_per_gpu": NCTX, "async_solve": not args.sync_solve,
                        "pairs_ok_fraction": ok_frac, "smooth_passes": args.smooth,
                        "fast_threshold_sharing_in_pair": not args.no_temporal, "fast_threshold_hint_across_calls": not args.no_temporal,
                        "no_temporal_value": no_temporal_value,

@@ -75,15 +75,17 @@ __device__ __forceinline__ int mad24s(int a, int b, int c) {   // signed a*b + c
 // XCD-aware workgroup order.  The dispatcher deals workgroups round-robin to the 8 XCDs (linear id n -> XCD n % 8),
 // each with its own L2: neighbouring tiles of one image then sit on eight different L2s, every shared cache line is
 // fetched (and every partial line written back) once per XCD and DRAM sees eight interleaved walks.  Remapped, XCD k
-// works through one contiguous eighth of the (frame, tile) sequence.  Measured with tools/ubench/bw_tile.hip on the
-// shape of k_gray_pyr1 (480 B x 40 rows): 3.8 -> 5.2 TB/s; on 240 B x 80 rows: 2.5 -> 4.8 TB/s.  Bijective for any total.
+// works through one contiguous eighth of the frames, tile after tile.  Measured with tools/ubench/bw_tile.hip on the
+// shape of k_gray_pyr1 (480 B x 40 rows): 3.8 -> 5.2 TB/s; on 240 B x 80 rows: 2.5 -> 4.8 TB/s.
+// Division-free: BOTH grid dimensions are launched rounded up to a multiple of 8 (xcd_grid), so XCD = blockIdx.x & 7,
+// and the caller drops the (tile, frame) pairs past the real counts.
 __device__ __forceinline__ void xcd_order(int& tile, int& frame) {
-  const uint32_t gx = gridDim.x, total = gx * gridDim.y;
-  const uint32_t n = blockIdx.y * gx + blockIdx.x;
-  const uint32_t xcd = n & 7u, slot = n >> 3, fl = total >> 3, rem = total & 7u;
-  const uint32_t v = xcd * fl + min(xcd, rem) + slot;
-  frame = (int)(v / gx); tile = (int)(v - (uint32_t)frame * gx);
+  const uint32_t x = blockIdx.x, y = blockIdx.y;
+  tile = (int)((y & 7u) * (gridDim.x >> 3) + (x >> 3));
+  frame = (int)((x & 7u) * (gridDim.y >> 3) + (y >> 3));
 }
+// q = v / d for v * d < 2^20 (tile index / tiles per row), magic = floor(2^20 / d) + 1 from the host
+__device__ __forceinline__ int div_magic20(int v, int magic) { return (int)(((uint32_t)v * (uint32_t)magic) >> 20); }
 #define PD_W 128
 #define PD_H 32
 #define PD_SW 192   // staged source row bytes (multiple of 16, >= 1.2*128 + 4 + 15 of slack and alignment)
@@ -96,19 +98,21 @@ __device__ __forceinline__ int lin_ofs_estimate(int v, int ssize, int dsize) {
 
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t src_off,
                                                   int src_stride, int sw, int sh, int64_t dst_off, int dst_stride, int dw,
-                                                  int dh, int tiles_x, const int* __restrict__ xofs,
-                                                  const int* __restrict__ xc1, const int* __restrict__ yofs,
-                                                  const int* __restrict__ yc1) {
+                                                  int dh, int tiles_x, int tx_magic, int ntiles, int nframes,
+                                                  const int* __restrict__ xofs, const int* __restrict__ xc1,
+                                                  const int* __restrict__ yofs, const int* __restrict__ yc1) {
   __shared__ uint32_t tile32[PD_SH * PD_SW / 4];
   __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
   int f, bt;
   xcd_order(bt, f);
-  const int ty = bt / tiles_x, tx = bt - ty * tiles_x;
+  if (bt >= ntiles || f >= nframes) return;             // grid padding (workgroup-uniform)
+  const int ty = div_magic20(bt, tx_magic), tx = bt - ty * tiles_x;
   const int x0 = tx * PD_W, y0 = ty * PD_H;
   const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PD_H, dh) - 1;
-  // source footprint, bounded without touching memory (one pixel of slack on each side)
-  const int sx0 = max(lin_ofs_estimate(x0, sw, dw) - 1, 0) & ~15, sy0 = max(lin_ofs_estimate(y0, sh, dh) - 1, 0);
-  const int ex = min(lin_ofs_estimate(x1, sw, dw) + 2, sw - 1), ey = min(lin_ofs_estimate(y1, sh, dh) + 2, sh - 1);
+  // source footprint straight from the tap tables (scalar loads; a right / bottom edge tap is encoded as
+  // (size - 2, weight 256), so ofs + 1 is always inside the source)
+  const int sx0 = xofs[x0] & ~15, sy0 = yofs[y0];
+  const int ex = xofs[x1] + 1, ey = yofs[y1] + 1;
   const int ncol16 = (ex - sx0) / 16 + 1, nrow = ey - sy0 + 1;     // <= PD_SW/16 = 11, <= PD_SH
   uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;   // wave-uniform 64-bit bases; per-lane offsets stay 32-bit
   const uint8_t* simg = base + src_off + sx0;
@@ -177,13 +181,15 @@ __global__ __launch_bounds__(256) void k_gray_pyr1(const uint8_t* __restrict__ s
                                                    int64_t frame_stride, int aligned4, uint8_t* __restrict__ pyr,
                                                    int64_t pyr_frame_bytes, int s_stride, int sw, int sh, int64_t dst_off,
                                                    int dst_stride, int dw, int dh, int tiles_x, int tiles_y,
+                                                   int tx_magic, int nframes,
                                                    const int* __restrict__ xofs, const int* __restrict__ xc1,
                                                    const int* __restrict__ yofs, const int* __restrict__ yc1) {
   __shared__ uint32_t tile32[GP_SH * GP_SW / 4];
   __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
   int f, bt;
   xcd_order(bt, f);
-  const int ty = bt / tiles_x, tx = bt - ty * tiles_x;
+  if (bt >= tiles_x * tiles_y || f >= nframes) return;  // grid padding (workgroup-uniform)
+  const int ty = div_magic20(bt, tx_magic), tx = bt - ty * tiles_x;
   const int x0 = tx * PD_W, y0 = ty * PD_H;
   const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PD_H, dh) - 1;
   const int rx0 = xofs[x0] & ~3, ry0 = yofs[y0];
@@ -812,6 +818,7 @@ struct SelectArgs {
   uint32_t* tmp_meta; float* tmp_resp; int* lvl_count;   // per-level staging (segments at EvhLevel.kp_base)
   int kcap;
   int k1cap, k2cap;   // LDS capacities of k_select (stage-1 / stage-2 survivors of one level)
+  int nframes;        // real frame count (the grid of k_select is padded, xcd_grid)
 };
 
 __device__ __forceinline__ float harris_response(const uint8_t* img, int stride, int x0, int y0) {
@@ -896,6 +903,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs A) {
   __shared__ int sh_cut[12];
   int l, f;                      // the eight levels of a frame on one XCD: 0.54 -> 0.45 ms
   xcd_order(l, f);
+  if (f >= A.nframes) return;    // grid padding (workgroup-uniform)
   const int tid = threadIdx.x;
   const EvhLevel L = A.lv[l];
   const uint32_t* cand = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
@@ -1245,6 +1253,9 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs 
 #undef WAVE_LDS_SYNC
 }
 
+// host side of xcd_order / div_magic20
+dim3 xcd_grid(int tiles, int frames) { return dim3((unsigned)((tiles + 7) & ~7), (unsigned)((frames + 7) & ~7)); }
+int magic20(int d) { return (1 << 20) / d + 1; }   // exact for v * d < 2^20: at most 4095 / 128 x 4095 / 32 tiles
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1260,13 +1271,15 @@ int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int
     const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;
     const int* t = c->d_tabs + D.tab_off;
     if (channels == 3 && aligned4 && (L.w & 3) == 0)
-      hipLaunchKernelGGL(k_gray_pyr1<true>, dim3(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, d_frames, channels,
+      hipLaunchKernelGGL(k_gray_pyr1<true>, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, d_frames, channels,
                        row_stride, frame_stride, aligned4, c->d_pyr, c->g.pyr_frame_bytes, L.stride, L.w, L.h, D.off,
-                       D.stride, D.w, D.h, tiles_x, tiles_y, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
+                       D.stride, D.w, D.h, tiles_x, tiles_y, magic20(tiles_x), nframes, t, t + D.w, t + 2 * D.w,
+                       t + 2 * D.w + D.h);
     else
-      hipLaunchKernelGGL(k_gray_pyr1<false>, dim3(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, d_frames, channels,
+      hipLaunchKernelGGL(k_gray_pyr1<false>, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, d_frames, channels,
                        row_stride, frame_stride, aligned4, c->d_pyr, c->g.pyr_frame_bytes, L.stride, L.w, L.h, D.off,
-                       D.stride, D.w, D.h, tiles_x, tiles_y, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
+                       D.stride, D.w, D.h, tiles_x, tiles_y, magic20(tiles_x), nframes, t, t + D.w, t + 2 * D.w,
+                       t + 2 * D.w + D.h);
   } else {
     int quads = ((L.w + 3) / 4) * L.h;
     dim3 grid((quads + 255) / 256, nframes);
@@ -1283,9 +1296,9 @@ int evh_launch_pyramid(evh_ctx* c, int nframes) {
     const EvhLevel& D = c->g.lv[l];
     const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;
     const int* t = c->d_tabs + D.tab_off;   // xofs | xc1 | yofs | yc1 (linear_exact_tab in evh_api.hip)
-    hipLaunchKernelGGL(k_pyr_down, dim3(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
-                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x, t, t + D.w,
-                       t + 2 * D.w, t + 2 * D.w + D.h);
+    hipLaunchKernelGGL(k_pyr_down, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
+                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x,
+                       magic20(tiles_x), tiles_x * tiles_y, nframes, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
     EVH_HIP(c, hipGetLastError());
   }
   return EVH_SUCCESS;
@@ -1346,7 +1359,8 @@ int evh_launch_select(evh_ctx* c, int nframes) {
   A.k1cap = std::min(EVH_K1CAP, std::max(1024, (4 * q0 + 63) / 64 * 64));
   A.k2cap = c->kcap;
   const size_t lds = sizeof(uint32_t) * 2 * ((size_t)A.k1cap + A.k2cap);
-  hipLaunchKernelGGL(k_select, dim3(EVH_NLEVELS, nframes), dim3(256), lds, c->stream, A);
+  A.nframes = nframes;
+  hipLaunchKernelGGL(k_select, xcd_grid(EVH_NLEVELS, nframes), dim3(256), lds, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
