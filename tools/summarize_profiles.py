@@ -19,6 +19,8 @@ out = os.path.join(root, "profiles")
 
 
 def short(name):
+    if name.startswith("void "):               # template instantiations are printed with their return type
+        name = name[5:]
     if name.startswith("(anonymous namespace)::"):
         name = name[len("(anonymous namespace)::"):]
     return name.split("(")[0].split("<")[0][:60]
