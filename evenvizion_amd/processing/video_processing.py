@@ -2,8 +2,8 @@
 
 get_homography_dict keeps the reference signature and result layout
     {frame_no: {"H": 3x3 list}, ..., "resize_info": {"h", "w"}}       (first key is 2)
-but instead of one frame pair per Python iteration it reads the capture in chunks, uploads a chunk once, and runs
-the whole per-pair body on the GPU (evh_stream_homography_batch_resized: imutils.resize fused into the ingest kernel): ORB on every frame once
+but instead of one frame pair per Python iteration it reads the capture in chunks (double-buffered: reading and
+uploading chunk i+1 overlap the GPU work on chunk i), uploads a chunk once, and runs the whole per-pair body on the GPU (evh_stream_homography_batch_resized: imutils.resize fused into the ingest kernel): ORB on every frame once
 (the reference recomputes each frame's features twice), matching / RANSAC #1 / static filter for all
 pairs of the chunk in parallel, and the final RANSAC as the sequential scan the running superposition requires
 (utils.py:351-358, video_processing.py:102-103).  Consecutive chunks overlap by one frame and carry
@@ -47,49 +47,89 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     # geometry), so a 4K source with resize_width=400 allocates 400-wide buffers
     ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures)
     dev = runtime.device()
-    H_dev = torch.empty(chunk_frames - 1, 9, dtype=torch.float64, device=dev)
-    st_dev = torch.empty(chunk_frames - 1, dtype=torch.int32, device=dev)
+    # Double-buffered chunk pipeline: while the GPU works on chunk i the host reads chunk i+1 from the capture into
+    # pinned memory and its upload runs on a copy stream; results come back through pinned buffers.  Chunk i is
+    # launched BEFORE the results of chunk i-1 are collected, so the device queue never drains.
+    B = runtime.staging((chunk_frames,) + first.shape, dev)
+    host, host_np, devbuf = B["host"], B["host_np"], B["dev"]
+    H_dev, st_dev, H_host, st_host = B["H_dev"], B["st_dev"], B["H_host"], B["st_host"]
+    copy_stream, up_done, all_done = B["copy_stream"], B["up_done"], B["all_done"]
     state = torch.zeros(18, dtype=torch.float64, device=dev)
+    cuda = dev.type == "cuda"          # (the host-loop unit test drives this function on the CPU with a scripted context)
+    cur = torch.cuda.current_stream(dev) if cuda else None
 
     homography_dict = {}
-    pending = [first]
-    frame_no = 1            # 1-based index of the newest frame already paired
-    have_state = False
-    exhausted = False
-    while not exhausted:
-        while len(pending) < chunk_frames:
-            ok, frame = capture.read()
-            if not ok:
-                exhausted = True
-                break
-            pending.append(np.ascontiguousarray(frame, np.uint8))
-        n = len(pending)
-        if n < 2:
-            break
-        big = runtime.to_device(np.stack(pending))
-        # K0 fused into the ingest kernel: level 0 comes straight from the full-size frames (N2); equal sizes are the
-        # plain gray conversion
-        ctx.stream_homography_batch(big, H_dev, st_dev, state_in=state if have_state else None, state_out=state,
-                                    nfeatures=nfeatures, resize_to=(dw, dh))
-        ctx.synchronize()
-        Hs = H_dev[:n - 1].cpu().numpy().reshape(-1, 3, 3)
-        sts = st_dev[:n - 1].cpu().numpy()
-        for k in range(n - 1):
-            frame_no += 1
+    frame_no = [1]          # 1-based index of the newest frame already paired
+
+    def collect(jb, nb):
+        if cuda:
+            all_done[jb].synchronize()
+        Hs = H_host[jb][:nb - 1].numpy().reshape(-1, 3, 3)
+        sts = st_host[jb][:nb - 1].numpy()
+        for k in range(nb - 1):
+            frame_no[0] += 1
+            fno = frame_no[0]
             if sts[k] == PAIR_CAPACITY:
                 # not a "no homography" outcome of the reference: a frame delivered more tied key points than a frame
                 # slot holds (see include/evhip.h, EVH_PAIR_CAPACITY) -- repeating H_prev would hide a wrong result
                 raise EvhError("frame %d or %d holds more key points (ties at the retainBest cut) than a frame slot "
-                               "of this context; raise nfeatures capacity" % (frame_no - 1, frame_no))
+                               "of this context; raise nfeatures capacity" % (fno - 1, fno))
             if sts[k] != PAIR_OK:
-                logging.info("pair ending at frame %d: no homography (status %d)", frame_no, int(sts[k]))
+                logging.info("pair ending at frame %d: no homography (status %d)", fno, int(sts[k]))
                 if not none_H_processing or not np.all(np.isfinite(Hs[k])):
                     # reference behaviour (video_processing.py:94-101): H stays None and None.tolist() raises --
                     # always for none_H_processing=False, and for a failing FIRST pair otherwise
                     raise AttributeError("'NoneType' object has no attribute 'tolist' (no homography for frame %d, "
-                                         "status %d)" % (frame_no, int(sts[k])))
-            homography_dict[frame_no] = {"H": Hs[k].tolist()}
-        have_state = True
-        pending = [pending[-1]]
+                                         "status %d)" % (fno, int(sts[k])))
+            homography_dict[fno] = {"H": Hs[k].tolist()}
+
+    j, n = 0, 1
+    host_np[0][0] = first
+    have_state = False
+    exhausted = False
+    inflight = None
+    try:
+        while True:
+            while n < chunk_frames and not exhausted:
+                ok, frame = capture.read()
+                if not ok:
+                    exhausted = True
+                    break
+                frame = np.asarray(frame, np.uint8)
+                if frame.shape != first.shape:
+                    raise ValueError("frame %d has shape %s, the first frame %s" % (frame_no[0] + n, frame.shape, first.shape))
+                host_np[j][n] = frame                  # the one host copy: straight into pinned memory
+                n += 1
+            launched = None
+            if n >= 2:
+                if cuda:
+                    with torch.cuda.stream(copy_stream):
+                        devbuf[j][:n].copy_(host[j][:n], non_blocking=True)
+                        up_done[j].record(copy_stream)
+                    cur.wait_event(up_done[j])
+                else:
+                    devbuf[j][:n].copy_(host[j][:n])
+                # K0 fused into the ingest kernel: level 0 comes straight from the full-size frames (N2); equal sizes
+                # are the plain gray conversion
+                ctx.stream_homography_batch(devbuf[j][:n], H_dev[j], st_dev[j], state_in=state if have_state else None,
+                                            state_out=state, nfeatures=nfeatures, resize_to=(dw, dh))
+                if cuda:
+                    ctx.order_torch_after()
+                H_host[j][:n - 1].copy_(H_dev[j][:n - 1], non_blocking=True)
+                st_host[j][:n - 1].copy_(st_dev[j][:n - 1], non_blocking=True)
+                if cuda:
+                    all_done[j].record(cur)
+                have_state = True
+                launched = (j, n)
+            if inflight is not None:
+                collect(*inflight)
+            inflight = launched
+            if inflight is None:
+                break
+            host_np[1 - j][0] = host_np[j][n - 1]      # consecutive chunks overlap by one frame
+            j, n = 1 - j, 1
+    finally:
+        if cuda:
+            torch.cuda.synchronize(dev)                 # nothing of this call is left in flight on the shared buffers
     homography_dict["resize_info"] = {"h": dh, "w": dw}
     return homography_dict

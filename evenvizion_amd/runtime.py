@@ -44,8 +44,37 @@ def to_device(array):
     return torch.from_numpy(np.ascontiguousarray(array)).to(device())
 
 
+_staging = {}
+
+
+def staging(shape, dev):
+    """Two pinned host chunks, two device chunks, result buffers, a copy stream and events for the chunk pipeline of
+    get_homography_dict; cached per chunk shape (pinning GBs of host memory is not free)."""
+    import torch
+    key = (tuple(shape), str(dev))
+    if key not in _staging:
+        _staging.clear()                      # one shape at a time: a new video size replaces the old buffers
+        npairs = shape[0] - 1
+        cuda = torch.device(dev).type == "cuda"
+        pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
+        host = [pin(torch.empty(shape, dtype=torch.uint8)) for _ in range(2)]
+        _staging[key] = {
+            "host": host, "host_np": [t.numpy() for t in host],
+            "dev": [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(2)],
+            "H_dev": [torch.empty(npairs, 9, dtype=torch.float64, device=dev) for _ in range(2)],
+            "st_dev": [torch.empty(npairs, dtype=torch.int32, device=dev) for _ in range(2)],
+            "H_host": [pin(torch.empty(npairs, 9, dtype=torch.float64)) for _ in range(2)],
+            "st_host": [pin(torch.empty(npairs, dtype=torch.int32)) for _ in range(2)],
+            "copy_stream": torch.cuda.Stream(device=dev) if cuda else None,
+            "up_done": [torch.cuda.Event() for _ in range(2)] if cuda else None,
+            "all_done": [torch.cuda.Event() for _ in range(2)] if cuda else None,
+        }
+    return _staging[key]
+
+
 def reset():
     global _ctx, _cfg
     if _ctx is not None:
         _ctx.close()
     _ctx, _cfg = None, None
+    _staging.clear()
