@@ -37,6 +37,12 @@ if f:
     with open(f) as fi, open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as fo:
         fo.write(fi.read())
 
+# 1b. the stream workload (bench.py --config 3)
+f = find("stats3", "*kernel_stats.csv")
+if f:
+    with open(f) as fi, open(os.path.join(out, tag + "_kernel_stats_cfg3.csv"), "w") as fo:
+        fo.write(fi.read())
+
 # 2. PMC passes
 def per_kernel(sub, counter):
     f = find(sub, "*counter_collection.csv")
