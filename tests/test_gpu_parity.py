@@ -790,6 +790,49 @@ def test_odd_and_small_sizes_full_path(w, h):
         c.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 7, 9, 16])   # covers every width residue mod 4 x {gray, BGR}
+def test_random_geometry_sweep(seed):
+    """Seeded random geometry: frame sizes from 80x80 to 640x400 (widths with every residue mod 4), 2..9 frames per
+    call (the XCD-ordered grids are padded to multiples of 8 in both dimensions), gray and BGR input, 300..700 key
+    points.  Every frame's pyramid, key points and descriptors and the whole stream of homographies must equal the
+    oracle's."""
+    from evenvizion_amd._lib import Context
+    rng = np.random.default_rng(seed)
+    w = int(rng.integers(80, 641)); h = int(rng.integers(80, 401))
+    nfr = int(rng.choice([2, 3, 5, 9])); cn = int(rng.choice([1, 3])); nfeat = int(rng.integers(300, 701))
+    gray, _ = S.make_stream(seed, nfr, w, h)
+    if rng.random() < 0.3:                               # sometimes hard content: uniform noise frames, shifted
+        base = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        gray = np.stack([np.roll(base, 2 * i, axis=1) for i in range(nfr)])
+    frames = gray if cn == 1 else S.gray_to_bgr(gray)
+    want_gray = gray if cn == 1 else np.stack([O.bgr2gray(f) for f in frames])
+    c = Context(device=0, max_w=w, max_h=h, max_features=nfeat, max_frames=nfr)
+    try:
+        n = nfr - 1
+        H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch(dev(frames), H, st, nfeatures=nfeat)
+        c.synchronize()
+        for f in range(nfr):
+            pyr = O.orb_pyramid(want_gray[f])
+            for l in range(8):
+                assert np.array_equal(c.download_level(f, l), pyr[l]), (w, h, cn, f, l)
+            o = O.orb_detect(want_gray[f], nfeatures=nfeat)
+            if len(o["xy"]) == 0:
+                assert c.lib.evh_orb_count(c.h, f) == 0
+            else:
+                g = c.orb_download(f)
+                assert np.array_equal(g["xy"], o["xy"]) and np.array_equal(g["desc"], o["desc"]), (w, h, cn, f)
+        Ho, so, rc = O.stream_gray(want_gray, nfeatures=nfeat)
+        assert np.array_equal(st.cpu().numpy(), so), (w, h, cn, nfr)
+        Hg = H.cpu().numpy().reshape(-1, 3, 3)
+        for p_ in range(n):
+            if so[p_] == 0:
+                assert np.allclose(Hg[p_], Ho[p_], rtol=1e-9, atol=1e-12), (w, h, cn, p_)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("cn", [1, 3])
 def test_unaligned_and_padded_input_layout(ctx, cn):
     """Frames handed over with an odd base address, padded rows and padded frames take the byte-wise gray path and
