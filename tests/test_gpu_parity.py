@@ -508,6 +508,65 @@ def test_two_phase_stream_equals_whole_stream(ctx):
     assert np.allclose(H.cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
 
 
+def test_config3_1080p_two_phase_stream_2000kp():
+    """BASELINE.json configs[3] on its own workload shape: one 1920x1080 STREAM, ORB 2000, split the way two GPUs
+    would take it (phase 1 on two blocks that overlap by one frame, ONE scan over the gathered static rows).  Equal,
+    bit for bit, to the single-call stream path, and equal to the oracle stream."""
+    from evenvizion_amd._lib import Context
+    from evenvizion_amd.sharding import stream_block
+    frames, _ = S.make_stream(31, 5, 1920, 1080)
+    n = len(frames) - 1
+    c = Context(device=0, max_w=1920, max_h=1080, max_features=2000, max_frames=len(frames))
+    try:
+        d = dev(frames)
+        H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch(d, H, st, nfeatures=2000)
+        c.synchronize()
+        parts = []
+        for r in range(2):
+            f_lo, f_hi, p_lo, p_hi = stream_block(len(frames), r, 2)
+            parts.append(c.stream_static_batch(d[f_lo:f_hi].contiguous(), nfeatures=2000))
+            assert parts[-1][0].shape[0] == p_hi - p_lo
+        rows = torch.cat([p_[0] for p_ in parts]); counts = torch.cat([p_[1] for p_ in parts]); st1 = torch.cat([p_[2] for p_ in parts])
+        H2, st2 = c.stream_scan(rows, counts, st1)
+        c.synchronize()
+        assert torch.equal(st2, st) and torch.equal(H2, H)
+        Ho, so, rc = O.stream_gray(frames, nfeatures=2000)
+        assert rc == -1 and np.array_equal(st.cpu().numpy(), so) and (so == 0).all()
+        assert np.allclose(H.cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
+    finally:
+        c.close()
+
+
+def test_config4_4k_streams_4000kp():
+    """BASELINE.json configs[4] on its own workload shape: 3840x2160 STREAMS, ORB 4000 -- two streams of three frames
+    through the multi-stream entry (concurrent scans) and one of them through the single-stream entry; statuses and H
+    equal to the oracle stream."""
+    from evenvizion_amd._lib import Context
+    w, h, F = 3840, 2160, 3
+    s0, _ = S.make_stream(41, F, w, h)
+    s1, _ = S.make_stream(42, F, w, h)
+    c = Context(device=0, max_w=w, max_h=h, max_features=4000, max_frames=2 * F)
+    try:
+        both = dev(np.stack([s0, s1]))
+        H = torch.zeros(2, F - 1, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((2, F - 1), -1, dtype=torch.int32, device="cuda")
+        c.multi_stream_homography_batch(both, H, st, nfeatures=4000)
+        c.synchronize()
+        H1 = torch.zeros(F - 1, 9, dtype=torch.float64, device="cuda")
+        st1 = torch.full((F - 1,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch(both[1], H1, st1, nfeatures=4000)
+        c.synchronize()
+        assert torch.equal(H1, H[1]) and torch.equal(st1, st[1])
+        for i, fr in enumerate((s0, s1)):
+            Ho, so, rc = O.stream_gray(fr, nfeatures=4000)
+            assert rc == -1 and np.array_equal(st[i].cpu().numpy(), so) and (so == 0).all()
+            assert np.allclose(H[i].cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
+    finally:
+        c.close()
+
+
 def test_multi_stream_batch_equals_each_stream_alone():
     """evh_multi_stream_homography_batch: S streams scanned concurrently (one wavefront each) == each stream through
     evh_stream_homography_batch on its own, bit for bit, including carried state and a stream with a failing pair."""
