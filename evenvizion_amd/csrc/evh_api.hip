@@ -126,8 +126,11 @@ int configure(evh_ctx* c, int w, int h, int nfeatures) {
     linear_exact_tab(S.w, D.w, &tabs[base], &tabs[base + D.w]);
     linear_exact_tab(S.h, D.h, &tabs[base + 2 * D.w], &tabs[base + 2 * D.w + D.h]);
   }
-  EVH_HIP(c, hipStreamSynchronize(c->stream));
-  EVH_HIP(c, hipMemcpy(c->d_tabs, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice));
+  // stream-ordered upload through pinned staging: kernels already enqueued keep the old tables, later ones see the new
+  EVH_HIP(c, hipEventSynchronize(c->ev_tabs));                       // the previous upload has left h_tabs
+  std::memcpy(c->h_tabs, tabs.data(), tabs.size() * sizeof(int));
+  EVH_HIP(c, hipMemcpyAsync(c->d_tabs, c->h_tabs, tabs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  EVH_HIP(c, hipEventRecord(c->ev_tabs, c->stream));
   c->g = g;
   c->geom_valid = true;
   return EVH_SUCCESS;
@@ -249,6 +252,9 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_cand, F * (size_t)gmax.cand_frame_entries));
   A_(dalloc(c, &c->d_cand_count, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_tabs, (size_t)tabn + 64));
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_tabs), ((size_t)tabn + 64) * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_tabs, hipEventDisableTiming) != hipSuccess)
+    return fail(EVH_ERR_HIP);
   A_(dalloc(c, &c->d_kp_xy, F * K * 2));
   A_(dalloc(c, &c->d_kp_meta, F * K));
   A_(dalloc(c, &c->d_kp_resp, F * K));
@@ -299,6 +305,8 @@ void evh_destroy(evh_ctx* c) {
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : c->prof_pool) (void)hipEventDestroy(e);
   if (c->solve_stream) { (void)hipStreamSynchronize(c->solve_stream); (void)hipStreamDestroy(c->solve_stream); }
+  if (c->h_tabs) (void)hipHostFree(c->h_tabs);
+  if (c->ev_tabs) (void)hipEventDestroy(c->ev_tabs);
   if (c->ev_match_done) (void)hipEventDestroy(c->ev_match_done);
   if (c->ev_solve_done) (void)hipEventDestroy(c->ev_solve_done);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -56,6 +56,8 @@ struct evh_ctx {
   uint32_t* d_cand = nullptr;     // [max_frames][cand_frame_entries]
   int* d_cand_count = nullptr;    // [max_frames][8]
   int* d_tabs = nullptr;          // resize tables for levels 1..7
+  int* h_tabs = nullptr;          // pinned staging of the same (configure() uploads stream-ordered, no host sync)
+  hipEvent_t ev_tabs = nullptr;   // the last upload out of h_tabs
   float* d_kp_xy = nullptr;       // [max_frames][kcap][2]
   uint32_t* d_kp_meta = nullptr;  // [max_frames][kcap]  level<<24 | y<<12 | x
   float* d_kp_resp = nullptr;     // [max_frames][kcap]
