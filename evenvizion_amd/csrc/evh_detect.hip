@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_pack(SelectArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K5 + K6: one wavefront per keypoint.  The 45x45 raw neighbourhood is staged in LDS once and serves the
+// K5 + K6: one wavefront per keypoint.  The 45x45 raw neighbourhood is staged in LDS once (16-byte loads) and serves the
 // intensity-centroid orientation (radius-15 disc), the 7x7 sigma-2 fixed-point Gaussian (only the 39x39 region
 // the steered taps can reach) and the 256 rotated BRIEF tests (4 x 64-lane ballots = the 32 descriptor bytes).
 struct DescribeArgs {
@@ -1123,7 +1123,7 @@ __device__ __forceinline__ void det_sincos(double x, double* so, double* co) {
 
 #define DP_R 22                 // raw neighbourhood radius
 #define DP_N (2 * DP_R + 1)     // 45
-#define DP_STRIDE 52            // 13 dwords per staged row (odd dword stride: row-per-lane reads are conflict-free)
+#define DP_STRIDE4 17           // dwords per staged row: 16 loaded + 1 (odd dword stride: row-per-lane reads are conflict-free)
 #define DB_R 19                 // blurred radius reachable by steered taps
 #define DB_N (2 * DB_R + 1)     // 39
 #define DH_STRIDE 41            // u16 per row of the horizontal-pass buffer (odd: conflict-free row-per-lane writes)
@@ -1135,10 +1135,11 @@ __device__ __forceinline__ int gauss7(int a0, int a1, int a2, int a3, int a4, in
 }
 
 __global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs A) {
-  // ONE LDS region per wave (3.7 KB), used in turn as the raw patch (45 x 52 B), the horizontal-pass buffer
+  // ONE LDS region per wave (3.7 KB), used in turn as the raw patch (45 x 68 B), the horizontal-pass buffer
   // (45 x 41 u16) and the blurred patch (39 x 39 B): every pass first loads all it needs into registers, a
   // wave-level fence follows, only then does it store the next form over the same words.  14.8 KB per workgroup.
   __shared__ uint32_t patch32[DW_PER_BLOCK][(DP_N * DH_STRIDE + 2) / 2 + 1];
+  static_assert(DP_N * DP_STRIDE4 <= (DP_N * DH_STRIDE + 2) / 2 + 1 && DB_N * DB_N <= 4 * ((DP_N * DH_STRIDE + 2) / 2 + 1), "forms share one region");
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* raw = patch32[wv];
   uint16_t* hb = reinterpret_cast<uint16_t*>(patch32[wv]);
@@ -1154,13 +1155,24 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs 
   const float inv = 1.f / L.scale;
   const int cx = (int)rintf(A.kp_xy[2 * o] * inv), cy = (int)rintf(A.kp_xy[2 * o + 1] * inv);
   const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-  const int xs = cx - DP_R, sh = xs & 3, xa = xs - sh;
+  // the 45-byte patch rows lie inside the 64 bytes from the 16-byte boundary below their first pixel: each row is
+  // four aligned 16-byte loads (180 per patch = 3 per lane, no division), stored with a 17-dword row stride
+  // (odd: the row-per-lane reads below are conflict-free).  A key point is >= 31 px from every border of its level
+  // and rows are padded to 64 bytes, so the window never leaves the level's rows.
+  const int xs = cx - DP_R, xa = xs & ~15, shq = (xs - xa) >> 2;
+  const uint32_t sh = (uint32_t)(xs & 3);
   {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(img + xa);
-    const int stride4 = L.stride >> 2;
-    for (int i = lane; i < DP_N * (DP_STRIDE / 4); i += 64) {
-      const int r = i / (DP_STRIDE / 4), c4 = i - r * (DP_STRIDE / 4);
-      raw[i] = src[mad24((uint32_t)(cy - DP_R + r), (uint32_t)stride4, (uint32_t)c4)];
+    const uint4* src = reinterpret_cast<const uint4*>(img + xa);
+    const int stride16 = L.stride >> 4;
+#pragma unroll
+    for (int k = 0; k < (DP_N * 4 + 63) / 64; k++) {
+      const int i = lane + 64 * k;
+      if (i < DP_N * 4) {
+        const int r = i >> 2, c = i & 3;
+        const uint4 v = src[mad24((uint32_t)(cy - DP_R + r), (uint32_t)stride16, (uint32_t)c)];
+        uint32_t* d = raw + r * DP_STRIDE4 + c * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
     }
   }
 #define WAVE_LDS_SYNC()                                    \
@@ -1173,7 +1185,7 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs 
   int m10 = 0, m01 = 0;
   uint32_t w[12];
   if (lane < DP_N) {
-    const uint32_t* rp = raw + lane * (DP_STRIDE / 4);
+    const uint32_t* rp = raw + lane * DP_STRIDE4 + shq;
 #pragma unroll
     for (int j = 0; j < 12; j++) w[j] = __builtin_amdgcn_alignbyte(rp[j + 1], rp[j], sh);
   }
@@ -1215,20 +1227,27 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs 
   for (int s = 32; s > 0; s >>= 1) { m10 += __shfl_xor(m10, s); m01 += __shfl_xor(m01, s); }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   WAVE_LDS_SYNC();
-  // ---- one lane per blurred column: vertical 7-tap pass, sliding down the 45 rows
-  int h[DP_N];
+  // ---- one lane per blurred column: vertical 7-tap pass down the 45 rows.  The column is held as PAIRS of
+  //      consecutive rows (h[2j] | h[2j+1] << 16: the second ds_read_u16 of a pair lands in the high half of the same
+  //      register), an output row is then four v_dot2_u32_u16 with the tap pairs (18,34)(49,55)(49,34)(18,0) or
+  //      (0,18)(34,49)(55,49)(34,18) -- the same integer as gauss7 on the seven values, 4 instead of 9 operations
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 P[(DP_N + 1) / 2];
   if (lane < DB_N) {
     const uint16_t* hc = hb + lane;
 #pragma unroll
-    for (int r = 0; r < DP_N; r++) h[r] = hc[r * DH_STRIDE];
+    for (int j = 0; j < DP_N / 2; j++) { P[j].x = hc[(2 * j) * DH_STRIDE]; P[j].y = hc[(2 * j + 1) * DH_STRIDE]; }
+    P[DP_N / 2].x = hc[(DP_N - 1) * DH_STRIDE]; P[DP_N / 2].y = 0;       // row 45 does not exist (its tap weight is 0)
   }
   WAVE_LDS_SYNC();      // every column is in registers: the region may now take the blurred patch
   if (lane < DB_N) {
+    const u16x2 WE[4] = {{18, 34}, {49, 55}, {49, 34}, {18, 0}}, WO[4] = {{0, 18}, {34, 49}, {55, 49}, {34, 18}};
 #pragma unroll
-    for (int r = 0; r < DB_N; r++) {
-      const int rr = r + (DP_R - DB_R);
-      const int sum = gauss7(h[rr - 3], h[rr - 2], h[rr - 1], h[rr], h[rr + 1], h[rr + 2], h[rr + 3]);
-      blurp[r * DB_N + lane] = (uint8_t)((sum + 32768) >> 16);
+    for (int r = 0; r < DB_N; r++) {              // output row r = taps on rows r .. r + 6 of the 45
+      uint32_t sum = 32768u;
+#pragma unroll
+      for (int q = 0; q < 4; q++) sum = __builtin_amdgcn_udot2(P[(r >> 1) + q], (r & 1) ? WO[q] : WE[q], sum, false);
+      blurp[r * DB_N + lane] = (uint8_t)(sum >> 16);
     }
   }
   WAVE_LDS_SYNC();
