@@ -378,7 +378,7 @@ __device__ __forceinline__ int fast_score_from_d(const i16 (&d)[16]) {
 
 
 struct FastLds {
-  uint32_t raw[FR_H * FR_DW];        // 40 x 36 dwords: rows y0-4.., columns x0-8..
+  alignas(16) uint32_t raw[FR_H * FR_DW];   // 36 rows x 36 dwords: rows y0-4.., columns x0-8.. (16-byte staging stores)
   uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
   // lst: NMS output, at most one corner per 2x2 block (896 entries).  The lifted path uses the same words first as
   // its queue of quads with a pixel that passes the pre-test (<= 1020 entries, quad index | pass bits << 16): the
@@ -388,31 +388,30 @@ struct FastLds {
   int lcnt, gbase, qcnt, scnt;
 };
 
-// stage rows y0-4 .. y0+FT_H+3, columns x0-8 .. x0+135 with 8-byte loads (data outside the image reads as 0: it
+// stage rows y0-4 .. y0+FT_H+3, columns x0-8 .. x0+135 with 16-byte loads (data outside the image reads as 0: it
 // only feeds pixels whose centre is outside the testable range, which are never scored); clears the counters
 __device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const EvhLevel& L, int x0, int y0) {
   if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; S.scnt = 0; }
-  const int stride8 = L.stride >> 3;
-  const uint2* img8 = reinterpret_cast<const uint2*>(img);
-  if (y0 >= 4 && y0 + FT_H + 4 <= L.h && x0 >= 8 && x0 + FT_W + 8 <= L.stride) {   // workgroup-uniform: every staged byte exists
-    // item i = (row i / 18, 8-byte column i % 18); +256 items = +14 rows +4 columns
-    int r = (int)threadIdx.x / (FR_DW / 2), c8 = (int)threadIdx.x - r * (FR_DW / 2);
-    const uint2* p0 = img8 + mad24((uint32_t)(y0 - 4), (uint32_t)stride8, (uint32_t)((x0 - 8) >> 3));
+  // 16-byte items (x0 - 8 = 16 + 128 tx is 16-byte aligned, a staged row is 9 of them): item i = (row i / 9,
+  // column i % 9), 324 items = 2 per thread at most; +256 items = +28 rows +4 columns.  Rows are padded to 64 bytes,
+  // so an item is wholly inside [0, stride) or wholly outside.
+  static_assert(FR_DW % 4 == 0 && ((EVH_FAST_OX - 8) % 16) == 0 && (FT_W % 16) == 0, "16-byte staging");
+  constexpr int C16 = FR_DW / 4;
+  const int stride16 = L.stride >> 4;
+  // workgroup-uniform: every staged byte exists (all tiles but those on the right / bottom edge of a level)
+  const bool inside = y0 >= 4 && y0 + FT_H + 4 <= L.h && x0 >= 8 && x0 + FT_W + 8 <= L.stride;
+  int r = (int)threadIdx.x / C16, c16 = (int)threadIdx.x - r * C16;
+  const uint4* p0 = reinterpret_cast<const uint4*>(img) + mad24s(y0 - 4, stride16, (x0 - 8) >> 4);
 #pragma unroll
-    for (int j = 0; j < (FR_H * (FR_DW / 2) + 255) / 256; j++) {
-      if (j * 256 + (int)threadIdx.x < FR_H * (FR_DW / 2))
-        *reinterpret_cast<uint2*>(&S.raw[r * FR_DW + c8 * 2]) = p0[mad24((uint32_t)r, (uint32_t)stride8, (uint32_t)c8)];
-      r += 14; c8 += 4;
-      if (c8 >= FR_DW / 2) { c8 -= FR_DW / 2; r++; }
+  for (int j = 0; j < (FR_H * C16 + 255) / 256; j++) {
+    if (j * 256 + (int)threadIdx.x < FR_H * C16) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      const int y = y0 - 4 + r, x = x0 - 8 + c16 * 16;
+      if (inside || (x >= 0 && x < L.stride && y >= 0 && y < L.h)) v = p0[mad24s(r, stride16, c16)];
+      *reinterpret_cast<uint4*>(&S.raw[r * FR_DW + c16 * 4]) = v;
     }
-    return;
-  }
-  for (int i = threadIdx.x; i < FR_H * (FR_DW / 2); i += 256) {
-    const int r = i / (FR_DW / 2), c8 = i - r * (FR_DW / 2);
-    const int y = y0 - 4 + r, x = x0 - 8 + c8 * 8;
-    uint2 v = make_uint2(0u, 0u);
-    if (x >= 0 && x < L.stride && y >= 0 && y < L.h) v = img8[mad24((uint32_t)y, (uint32_t)stride8, (uint32_t)(x >> 3))];
-    *reinterpret_cast<uint2*>(&S.raw[r * FR_DW + c8 * 2]) = v;
+    r += 256 / C16; c16 += 256 % C16;
+    if (c16 >= C16) { c16 -= C16; r++; }
   }
 }
 
