@@ -223,8 +223,9 @@ const char* evh_last_error_string(const evh_ctx* ctx) { return ctx ? ctx->err.c_
 int evh_create(int device, int max_w, int max_h, int max_features, int max_frames, void* stream, evh_ctx** out) {
   if (!out) return evh_fail(nullptr, EVH_ERR_INVALID, "evh_create: out is NULL");
   *out = nullptr;
-  if (max_w < 64 || max_h < 64 || max_w >= 4096 || max_h >= 4096 || max_features < 1 || max_frames < 2)
-    return evh_fail(nullptr, EVH_ERR_INVALID, "evh_create: sizes out of range (64 <= w,h < 4096, frames >= 2)");
+  // frames are a grid dimension of every per-frame kernel (rounded up to a multiple of 8 by the XCD-ordered ones)
+  if (max_w < 64 || max_h < 64 || max_w >= 4096 || max_h >= 4096 || max_features < 1 || max_frames < 2 || max_frames > 65528)
+    return evh_fail(nullptr, EVH_ERR_INVALID, "evh_create: sizes out of range (64 <= w,h < 4096, 2 <= frames <= 65528)");
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return evh_fail(nullptr, EVH_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
   evh_ctx* c = new evh_ctx();

@@ -59,6 +59,7 @@ enum { EVH_MODE_INDEPENDENT_PAIRS = 0, EVH_MODE_STREAM = 1 };
 
 /* ---- context ------------------------------------------------------------------------------------------------ */
 /* stream: a hipStream_t to enqueue on, or NULL to let the context create its own non-blocking stream.          */
+/* 64 <= max_w, max_h < 4096; 2 <= max_frames <= 65528 (frames are a grid dimension); else EVH_ERR_INVALID.    */
 int evh_create(int device, int max_w, int max_h, int max_features, int max_frames, void* stream, evh_ctx** out);
 void evh_destroy(evh_ctx* ctx);
 const char* evh_last_error_string(const evh_ctx* ctx); /* ctx may be NULL: last error of evh_create */
