@@ -62,8 +62,8 @@ __global__ void k_gray_level0(const uint8_t* __restrict__ src, int channels, int
 // K2: pyramid level l from level l-1, resize(INTER_LINEAR_EXACT): 8.8 fixed-point weights per axis,
 // out = ((c0*s00 + c1*s01)*m0 + (c0*s10 + c1*s11)*m1 + 32768) >> 16.  Tables (host-computed): per dst column
 // (xofs, xc1), per dst row (yofs, yc1); edge replication is encoded in the tables.
-// Workgroup = 128 x 32 output pixels; the source footprint (<= 176 x 43 bytes at scale 1.2) is staged in LDS with
-// 16-byte loads, each thread then produces 4 rows x 4 pixels from LDS bytes and stores one dword per row.
+// Workgroup = 128 x 64 output pixels (PDN_H); the source footprint (<= 176 x 82 bytes at scale 1.2) is staged in LDS
+// with 16-byte loads, each thread then produces 8 rows x 4 pixels from LDS bytes and stores one dword per row.
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {   // a*b + c, a,b < 2^24 (half-rate VALU;
   uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;   // v_mul_lo_u32 / v_mad_u64_u32 are far slower)
 }
@@ -90,6 +90,12 @@ __device__ __forceinline__ int div_magic20(int v, int magic) { return (int)(((ui
 #define PD_H 32
 #define PD_SW 192   // staged source row bytes (multiple of 16, >= 1.2*128 + 4 + 15 of slack and alignment)
 #define PD_SH 44    // staged source rows (>= 1.2*32 + 5)
+// k_pyr_down: output rows per tile.  64 amortises the per-workgroup set-up (tap tables, footprint, ~160 scalar and
+// vector instructions) and the two halo rows over twice the pixels: 2.18 -> 1.95 ms for the six launches; 48 rows
+// 2.02, 96 rows 2.13, 128 rows 2.5 (LDS then allows 5 workgroups per CU).  k_gray_pyr1 keeps PD_H = 32: its BGR
+// staging lives in registers.
+#define PDN_H 64
+#define PDN_SH (PDN_H * 121 / 100 + 5)   // staged source rows
 // conservative integer estimate of floor(scale*(v+0.5)-0.5) with scale ~ ssize/dsize (only used to bound the source
 // footprint of a tile; the exact taps come from the host-built tables)
 __device__ __forceinline__ int lin_ofs_estimate(int v, int ssize, int dsize) {
@@ -101,19 +107,19 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
                                                   int dh, int tiles_x, int tx_magic, int ntiles, int nframes,
                                                   const int* __restrict__ xofs, const int* __restrict__ xc1,
                                                   const int* __restrict__ yofs, const int* __restrict__ yc1) {
-  __shared__ uint32_t tile32[PD_SH * PD_SW / 4];
-  __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
+  __shared__ uint32_t tile32[PDN_SH * PD_SW / 4];
+  __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PDN_H]; __shared__ int yc_s[PDN_H];
   int f, bt;
   xcd_order(bt, f);
   if (bt >= ntiles || f >= nframes) return;             // grid padding (workgroup-uniform)
   const int ty = div_magic20(bt, tx_magic), tx = bt - ty * tiles_x;
-  const int x0 = tx * PD_W, y0 = ty * PD_H;
-  const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PD_H, dh) - 1;
+  const int x0 = tx * PD_W, y0 = ty * PDN_H;
+  const int x1 = min(x0 + PD_W, dw) - 1, y1 = min(y0 + PDN_H, dh) - 1;
   // source footprint straight from the tap tables (scalar loads; a right / bottom edge tap is encoded as
   // (size - 2, weight 256), so ofs + 1 is always inside the source)
   const int sx0 = xofs[x0] & ~15, sy0 = yofs[y0];
   const int ex = xofs[x1] + 1, ey = yofs[y1] + 1;
-  const int ncol16 = (ex - sx0) / 16 + 1, nrow = ey - sy0 + 1;     // <= PD_SW/16 = 11, <= PD_SH
+  const int ncol16 = (ex - sx0) / 16 + 1, nrow = ey - sy0 + 1;     // <= PD_SW/16 = 11, <= PDN_SH
   uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;   // wave-uniform 64-bit bases; per-lane offsets stay 32-bit
   const uint8_t* simg = base + src_off + sx0;
   uint8_t* dimg = base + dst_off;
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
   if (threadIdx.x < PD_W) {
     const int xi = min(x0 + (int)threadIdx.x, dw - 1);
     xo_s[threadIdx.x] = xofs[xi] - sx0; xc_s[threadIdx.x] = xc1[xi];
-  } else if (threadIdx.x < PD_W + PD_H) {
+  } else if (threadIdx.x < PD_W + PDN_H) {
     const int r = threadIdx.x - PD_W, yi = min(y0 + r, dh - 1);
     yo_s[r] = yofs[yi] - sy0; yc_s[r] = yc1[yi];
   }
@@ -137,17 +143,17 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
     }
   }
   __syncthreads();
-  const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;     // 32 quads across, 8 groups of PD_H/8 rows down
+  const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;     // 32 quads across, 8 groups of PDN_H/8 rows down
   const int x = x0 + qx * 4;
   if (x >= dw) return;
   const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
 #pragma unroll
-  for (int rr = 0; rr < PD_H / 8; rr++) {
-    const int y = y0 + qy * (PD_H / 8) + rr;
+  for (int rr = 0; rr < PDN_H / 8; rr++) {
+    const int y = y0 + qy * (PDN_H / 8) + rr;
     if (y >= dh) break;
-    const uint8_t* r0 = tile + yo_s[qy * (PD_H / 8) + rr] * PD_SW;
+    const uint8_t* r0 = tile + yo_s[qy * (PDN_H / 8) + rr] * PD_SW;
     const uint8_t* r1 = r0 + PD_SW;
-    const int m1 = yc_s[qy * (PD_H / 8) + rr];
+    const int m1 = yc_s[qy * (PDN_H / 8) + rr];
     // (c0*a + c1*b)*m0 + (c0*a' + c1*b')*m1 + 32768, c0 = 256 - c1, m0 = 256 - m1: 24-bit multiply-adds only (a
     // multiply-add costs the same issue slot as a shift here); the result byte sits in bits 16..23 of v[i] and two
     // v_perm_b32 gather the four of them
@@ -1312,7 +1318,7 @@ int evh_launch_pyramid(evh_ctx* c, int nframes) {
   for (int l = c->level1_fused ? 2 : 1; l < EVH_NLEVELS; l++) {
     const EvhLevel& S = c->g.lv[l - 1];
     const EvhLevel& D = c->g.lv[l];
-    const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PD_H - 1) / PD_H;
+    const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PDN_H - 1) / PDN_H;
     const int* t = c->d_tabs + D.tab_off;   // xofs | xc1 | yofs | yc1 (linear_exact_tab in evh_api.hip)
     hipLaunchKernelGGL(k_pyr_down, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
                        c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x,
