@@ -96,14 +96,8 @@ __device__ __forceinline__ int div_magic20(int v, int magic) { return (int)(((ui
 // staging lives in registers.
 #define PDN_H 64
 #define PDN_SH (PDN_H * 121 / 100 + 5)   // staged source rows
-// conservative integer estimate of floor(scale*(v+0.5)-0.5) with scale ~ ssize/dsize (only used to bound the source
-// footprint of a tile; the exact taps come from the host-built tables)
-__device__ __forceinline__ int lin_ofs_estimate(int v, int ssize, int dsize) {
-  return ((2 * v + 1) * ssize - dsize) / (2 * dsize);
-}
-
 __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t src_off,
-                                                  int src_stride, int sw, int sh, int64_t dst_off, int dst_stride, int dw,
+                                                  int src_stride, int64_t dst_off, int dst_stride, int dw,
                                                   int dh, int tiles_x, int tx_magic, int ntiles, int nframes,
                                                   const int* __restrict__ xofs, const int* __restrict__ xc1,
                                                   const int* __restrict__ yofs, const int* __restrict__ yc1) {
@@ -1134,11 +1128,7 @@ __device__ __forceinline__ void det_sincos(double x, double* so, double* co) {
 #define DH_STRIDE 41            // u16 per row of the horizontal-pass buffer (odd: conflict-free row-per-lane writes)
 #define DW_PER_BLOCK 4
 
-// 7-tap sigma-2 kernel, symmetric: 18 34 49 55 49 34 18
-__device__ __forceinline__ int gauss7(int a0, int a1, int a2, int a3, int a4, int a5, int a6) {
-  return mad24s(18, a0 + a6, mad24s(34, a1 + a5, mad24s(49, a2 + a4, 55 * a3)));
-}
-
+// 7-tap sigma-2 kernel, symmetric: 18 34 49 55 49 34 18 (byte / 16-bit dot products in k_describe)
 __global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs A) {
   // ONE LDS region per wave (3.7 KB), used in turn as the raw patch (45 x 68 B), the horizontal-pass buffer
   // (45 x 41 u16) and the blurred patch (39 x 39 B): every pass first loads all it needs into registers, a
@@ -1321,7 +1311,7 @@ int evh_launch_pyramid(evh_ctx* c, int nframes) {
     const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PDN_H - 1) / PDN_H;
     const int* t = c->d_tabs + D.tab_off;   // xofs | xc1 | yofs | yc1 (linear_exact_tab in evh_api.hip)
     hipLaunchKernelGGL(k_pyr_down, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
-                       c->g.pyr_frame_bytes, S.off, S.stride, S.w, S.h, D.off, D.stride, D.w, D.h, tiles_x,
+                       c->g.pyr_frame_bytes, S.off, S.stride, D.off, D.stride, D.w, D.h, tiles_x,
                        magic20(tiles_x), tiles_x * tiles_y, nframes, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
     EVH_HIP(c, hipGetLastError());
   }
