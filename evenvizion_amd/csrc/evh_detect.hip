@@ -379,7 +379,7 @@ __device__ __forceinline__ int fast_score_from_d(const i16 (&d)[16]) {
 
 struct FastLds {
   alignas(16) uint32_t raw[FR_H * FR_DW];   // 36 rows x 36 dwords: rows y0-4.., columns x0-8.. (16-byte staging stores)
-  uint32_t score[FS_H * FS_DW];      // 34 x 34 quads of byte scores: rows y0-1.., columns x0-4..
+  alignas(16) uint32_t score[FS_H * FS_DW];   // 30 x 34 quads of byte scores: rows y0-1.., columns x0-4..
   // lst: NMS output, at most one corner per 2x2 block (896 entries).  The lifted path uses the same words first as
   // its queue of quads with a pixel that passes the pre-test (<= 1020 entries, quad index | pass bits << 16): the
   // queue is dead before NMS writes the list.
@@ -486,12 +486,14 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
   // byte j = pixel j passes) stay in registers and are queued once after the loop with one LDS atomic per wave
   uint32_t P[4];
   int sr = threadIdx.x / FS_DW, sq = threadIdx.x - sr * FS_DW;
+  static_assert((FS_H * FS_DW) % 4 == 0 && FS_H * FS_DW <= 1024, "one 16-byte store per thread clears the score plane");
+  if (threadIdx.x < FS_H * FS_DW / 4)                           // phase B overwrites the bytes that reach T
+    reinterpret_cast<uint4*>(S.score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int i = threadIdx.x + 256 * k;
     P[k] = 0;
     if (i < FS_H * FS_DW) {
-      S.score[i] = 0;                                           // phase B overwrites the bytes that reach T
       uint32_t cmask = 0x80808080u;
       bool rowok = true;
       if (!interior) {
@@ -560,11 +562,12 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
 }
 
 // lifted path NMS: only the (few) pixels that reached T are visited
+// (run by wave 0 alone: the list holds a few dozen pixels)
 __device__ __forceinline__ void fast_nms_scored(FastLds& S, const EvhLevel& L, int x0, int y0) {
   if (!((L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE))) return;
   const uint8_t* sc = reinterpret_cast<const uint8_t*>(S.score);
   const int n = min(S.scnt, FT_W * FT_H / 2);
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 64) {
     const int pos = S.scored[i];
     const int sr = pos / FQ_PITCH, sx = pos - sr * FQ_PITCH;
     if (sr < 1 || sr > FT_H || sx < 4 || sx >= 4 + FT_W) continue;     // halo pixels belong to neighbouring tiles
@@ -624,6 +627,22 @@ __device__ __forceinline__ void fast_emit(FastLds& S, const FastArgs& A, const E
     uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
     const int base = S.gbase;
     for (int i = threadIdx.x; i < n; i += 256)
+      if (base + i < L.cand_cap) out[base + i] = S.lst[i];
+  }
+}
+
+// the same by wave 0 alone (the other waves of the workgroup have left): wave-level ordering only, no barrier
+__device__ __forceinline__ void fast_emit_wave0(FastLds& S, const FastArgs& A, const EvhLevel& L, int f, int l) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int n = S.lcnt;
+  if (n > 0) {
+    int base = 0;
+    if (threadIdx.x == 0) base = atomicAdd(A.cand_count + f * EVH_NLEVELS + l, n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
+    for (int i = threadIdx.x; i < n; i += 64)
       if (base + i < L.cand_cap) out[base + i] = S.lst[i];
   }
 }
@@ -742,8 +761,13 @@ __global__ __launch_bounds__(256, 8) void k_fast_main(FastArgs A) {
   if (T > EVH_FAST_THR) {
     fast_lift_scores(S, L, x0, y0, T);
     __syncthreads();
-    if (S.scnt <= FT_W * FT_H / 2) fast_nms_scored(S, L, x0, y0);
-    else fast_nms_collect(S, L, x0, y0);          // the short list overflowed: the score plane itself is complete
+    if (S.scnt <= FT_W * FT_H / 2) {              // workgroup-uniform.  What is left is a few dozen scored pixels:
+      if (threadIdx.x >= 64) return;              // waves 1-3 are done (no barrier follows on this path), wave 0
+      fast_nms_scored(S, L, x0, y0);              // runs NMS and the emission on its own
+      fast_emit_wave0(S, A, L, f, l);
+      return;
+    }
+    fast_nms_collect(S, L, x0, y0);               // the short list overflowed: the score plane itself is complete
   } else {
     fast_dense_scores(S, L, x0, y0);
     __syncthreads();
