@@ -707,7 +707,11 @@ __global__ __launch_bounds__(256, 8) void k_fast_sample(FastArgs A) {
   if (Tp) fast_lift_scores(S, L, x0, y0, Tp);          // exact scores >= Tp, zero elsewhere
   else fast_dense_scores(S, L, x0, y0);
   __syncthreads();
-  fast_nms_collect(S, L, x0, y0);
+  if (Tp && S.scnt <= FT_W * FT_H / 2) {               // workgroup-uniform: the short list of scored pixels is complete
+    if (threadIdx.x < 64) fast_nms_scored(S, L, x0, y0);
+  } else {
+    fast_nms_collect(S, L, x0, y0);
+  }
   __syncthreads();
   const int n = S.lcnt;
   unsigned* h = A.shist + (int64_t)(f * EVH_NLEVELS + l) * 256;
