@@ -489,29 +489,35 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
   static_assert((FS_H * FS_DW) % 4 == 0 && FS_H * FS_DW <= 1024, "one 16-byte store per thread clears the score plane");
   if (threadIdx.x < FS_H * FS_DW / 4)                           // phase B overwrites the bytes that reach T
     reinterpret_cast<uint4*>(S.score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+  // two copies of the loop: the interior one (most tiles) is straight-line code, so the LDS reads of its four quads
+  // can be issued together instead of each behind its own range test
+  auto quads = [&](auto interior_tag) {
+    constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int i = threadIdx.x + 256 * k;
-    P[k] = 0;
-    if (i < FS_H * FS_DW) {
-      uint32_t cmask = 0x80808080u;
-      bool rowok = true;
-      if (!interior) {
-        const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
-        rowok = y >= 3 && y < L.h - 3;
-        const int lo = min(max(3 - xq, 0), 4), hi = max(min(L.w - 3 - xq, 4), 0);   // valid pixels j in [lo, hi)
-        cmask = lo < hi ? (0x80808080u << (8 * lo)) & (0x80808080u >> (8 * (4 - hi))) : 0u;
+    for (int k = 0; k < 4; k++) {
+      const int i = threadIdx.x + 256 * k;
+      P[k] = 0;
+      if (i < FS_H * FS_DW) {
+        uint32_t cmask = 0x80808080u;
+        bool rowok = true;
+        if constexpr (!INTERIOR) {
+          const int y = y0 - 1 + sr, xq = x0 - 4 + sq * 4;
+          rowok = y >= 3 && y < L.h - 3;
+          const int lo = min(max(3 - xq, 0), 4), hi = max(min(L.w - 3 - xq, 4), 0);   // valid pixels j in [lo, hi)
+          cmask = lo < hi ? (0x80808080u << (8 * lo)) & (0x80808080u >> (8 * (4 - hi))) : 0u;
+        }
+        if (INTERIOR || (rowok && cmask)) {
+          const uint32_t* p = S.raw + mad24((uint32_t)(sr + 3), FR_DW, (uint32_t)sq);    // centre row, dword of x = xq-4
+          const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
+          P[k] = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu, __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4) &
+                 cmask;
+        }
       }
-      if (rowok && cmask) {
-        const uint32_t* p = S.raw + mad24((uint32_t)(sr + 3), FR_DW, (uint32_t)sq);      // centre row, dword of x = xq-4
-        const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
-        P[k] = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu, __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4) &
-               cmask;
-      }
+      sr += 7; sq += 18;                                        // +256 quads = +7 rows +18 quads
+      if (sq >= FS_DW) { sq -= FS_DW; sr++; }
     }
-    sr += 7; sq += 18;                                          // +256 quads = +7 rows +18 quads
-    if (sq >= FS_DW) { sq -= FS_DW; sr++; }
-  }
+  };
+  if (interior) quads(std::true_type{}); else quads(std::false_type{});
   {
     const unsigned long long m0 = __ballot(P[0] != 0), m1 = __ballot(P[1] != 0), m2 = __ballot(P[2] != 0),
                              m3 = __ballot(P[3] != 0);
