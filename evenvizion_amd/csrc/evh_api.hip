@@ -182,6 +182,18 @@ int match_pairs(evh_ctx* c, int npairs, int q0, int qstep, int t0, int tstep) {
   return evh_launch_filter(c, F, npairs);
 }
 
+// context-owned scratch of the host-pointer entries (evh_transform_points, evh_superposition_scan,
+// evh_fixed_plane_field): grown on demand, reused across calls (those entries synchronise before returning)
+int ensure_scratch(evh_ctx* c, size_t bytes) {
+  if (bytes <= c->scratch_bytes) return EVH_SUCCESS;
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
+  const size_t want = std::max(bytes, (size_t)1 << 16);
+  EVH_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_scratch), want));
+  c->scratch_bytes = want;
+  return EVH_SUCCESS;
+}
+
 // entry points that reuse the pair buffers on the main stream first order themselves behind a pending async solve
 int join_solve(evh_ctx* c) {
   if (c->solve_pending) EVH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_solve_done, 0));
@@ -231,9 +243,11 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   evh_ctx* c = new evh_ctx();
   c->device = device; c->max_w = max_w; c->max_h = max_h; c->max_features = max_features; c->max_frames = max_frames;
   c->kcap = kcap_for(max_features);
-  if ((size_t)c->kcap * 5 * sizeof(int) > 150 * 1024) {     // k_filter keeps five int lists of kcap entries in LDS
+  // k_filter keeps five int lists of kcap entries in LDS; k_select 8 * (EVH_K1CAP + kcap) bytes of dynamic LDS next to
+  // ~5 KB of static arrays (both opt in to more than the default 64 KB at launch)
+  if ((size_t)c->kcap * 5 * sizeof(int) > 150 * 1024 || 8 * ((size_t)EVH_K1CAP + c->kcap) + 8 * 1024 > 160 * 1024) {
     delete c;
-    return evh_fail(nullptr, EVH_ERR_CAPACITY, "evh_create: max_features too large for the matching filter's LDS lists (<= 6000)");
+    return evh_fail(nullptr, EVH_ERR_CAPACITY, "evh_create: max_features too large for the LDS lists of the matching filter / key-point selection (<= 6000)");
   }
   int rc = EVH_SUCCESS;
   auto fail = [&](int code) { g_create_error = c->err; evh_destroy(c); return code; };
@@ -254,8 +268,10 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_cand_count, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_tabs, (size_t)tabn + 64));
   if (hipHostMalloc(reinterpret_cast<void**>(&c->h_tabs), ((size_t)tabn + 64) * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_tabs, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_tabs, hipEventDisableTiming) != hipSuccess) {
+    c->err = "evh_create: pinned table staging (hipHostMalloc) or its event could not be created";
     return fail(EVH_ERR_HIP);
+  }
   A_(dalloc(c, &c->d_kp_xy, F * K * 2));
   A_(dalloc(c, &c->d_kp_meta, F * K));
   A_(dalloc(c, &c->d_kp_resp, F * K));
@@ -301,7 +317,7 @@ void evh_destroy(evh_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
                   c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
-                  c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small};
+                  c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : c->prof_pool) (void)hipEventDestroy(e);
@@ -404,18 +420,16 @@ int evh_resize_area_u8c3(evh_ctx* c, const uint8_t* d_src, int sw, int sh, uint8
 int evh_fixed_plane_field(evh_ctx* c, const double* h_Hsup, int n, int w, int h, double* d_field, double* h_max) {
   if (!c || !h_Hsup || !h_max || n < 1 || w < 1 || h < 1) return evh_fail(c, EVH_ERR_INVALID, "evh_fixed_plane_field: bad argument");
   if (n > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "evh_fixed_plane_field: at most 65535 matrices per call");
-  double* d_H = nullptr; unsigned long long* d_max = nullptr;
-  EVH_HIP(c, hipMalloc(&d_H, sizeof(double) * 9 * (size_t)n));
-  hipError_t e = hipMalloc(&d_max, sizeof(unsigned long long) * (size_t)n);
-  if (e != hipSuccess) { (void)hipFree(d_H); return evh_fail(c, EVH_ERR_HIP, "hipMalloc failed"); }
+  { int sr = ensure_scratch(c, (sizeof(double) * 9 + sizeof(unsigned long long)) * (size_t)n); if (sr) return sr; }
+  double* d_H = reinterpret_cast<double*>(c->d_scratch);
+  unsigned long long* d_max = reinterpret_cast<unsigned long long*>(c->d_scratch + sizeof(double) * 9 * (size_t)n);
   std::vector<unsigned long long> keys(n);
   int rc = EVH_SUCCESS;
-  e = hipMemcpyAsync(d_H, h_Hsup, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  hipError_t e = hipMemcpyAsync(d_H, h_Hsup, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) rc = evh_launch_fixed_plane(c, d_H, n, w, h, d_field, d_max);
   if (e == hipSuccess && rc == EVH_SUCCESS)
     e = hipMemcpyAsync(keys.data(), d_max, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_H); (void)hipFree(d_max);
   if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("evh_fixed_plane_field: ") + hipGetErrorString(e));
   if (rc) return rc;
   for (int i = 0; i < n; i++) {
@@ -428,15 +442,14 @@ int evh_fixed_plane_field(evh_ctx* c, const double* h_Hsup, int n, int w, int h,
 
 int evh_superposition_scan(evh_ctx* c, const double* h_H, int n, double* h_out) {
   if (!c || !h_H || !h_out || n < 1) return evh_fail(c, EVH_ERR_INVALID, "evh_superposition_scan: bad argument");
-  double* d = nullptr;
   const size_t bytes = sizeof(double) * 9 * (size_t)n;
-  EVH_HIP(c, hipMalloc(&d, 2 * bytes));
+  { int sr = ensure_scratch(c, 2 * bytes); if (sr) return sr; }
+  double* d = reinterpret_cast<double*>(c->d_scratch);
   int rc = EVH_SUCCESS;
   hipError_t e = hipMemcpyAsync(d, h_H, bytes, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) rc = evh_launch_superposition_scan(c, d, n, d + 9 * (size_t)n);
   if (e == hipSuccess && rc == EVH_SUCCESS) e = hipMemcpyAsync(h_out, d + 9 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d);
   if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("evh_superposition_scan: ") + hipGetErrorString(e));
   return rc;
 }
@@ -449,8 +462,8 @@ int evh_transform_points(evh_ctx* c, const double* h_M, int nmat, const int32_t*
   for (int i = 0; i < n; i++)
     if (h_idx[i] < 0 || h_idx[i] >= nmat) return evh_fail(c, EVH_ERR_INVALID, "evh_transform_points: matrix index out of range");
   const size_t bm = sizeof(double) * 9 * (size_t)nmat, bp = sizeof(double) * 2 * (size_t)n, bi = sizeof(int32_t) * (size_t)n;
-  char* d = nullptr;
-  EVH_HIP(c, hipMalloc(&d, bm + 2 * bp + bi));
+  { int sr = ensure_scratch(c, bm + 2 * bp + bi); if (sr) return sr; }
+  char* d = c->d_scratch;
   double* d_M = reinterpret_cast<double*>(d);
   double* d_pts = reinterpret_cast<double*>(d + bm);
   double* d_out = reinterpret_cast<double*>(d + bm + bp);
@@ -462,7 +475,6 @@ int evh_transform_points(evh_ctx* c, const double* h_M, int nmat, const int32_t*
   if (e == hipSuccess) rc = evh_launch_transform_points(c, d_M, d_idx, d_pts, n, kx, ky, decimals, d_out);
   if (e == hipSuccess && rc == EVH_SUCCESS) e = hipMemcpyAsync(h_out, d_out, bp, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d);
   if (e != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("evh_transform_points: ") + hipGetErrorString(e));
   return rc;
 }
@@ -489,7 +501,7 @@ static int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw
   if (nframes < 1 || nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "nframes exceeds max_frames");
   if (channels != 1 && channels != 3) return evh_fail(c, EVH_ERR_INVALID, "channels must be 1 or 3");
   if (row_stride < (int64_t)sw * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
-  if (sw < w || sh < h || sw < 1 || sh < 1) return evh_fail(c, EVH_ERR_UNSUPPORTED, "the working size must not exceed the frame size");
+  if (sw < 1 || sh < 1) return evh_fail(c, EVH_ERR_INVALID, "empty source frame");
   if (nframes > 65535 || h > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "too many frames / rows for one launch");
   int rc = configure(c, w, h, nfeatures);
   if (rc) return rc;

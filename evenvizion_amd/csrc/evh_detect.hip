@@ -1408,6 +1408,9 @@ int evh_launch_select(evh_ctx* c, int nframes) {
   A.k2cap = c->kcap;
   const size_t lds = sizeof(uint32_t) * 2 * ((size_t)A.k1cap + A.k2cap);
   A.nframes = nframes;
+  if (lds > 48 * 1024)   // from ~3000 key points on (74.7 KB at 4000): opt in to more dynamic LDS than the default
+    EVH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
   hipLaunchKernelGGL(k_select, xcd_grid(EVH_NLEVELS, nframes), dim3(256), lds, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, c->stream, A);

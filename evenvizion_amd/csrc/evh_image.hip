@@ -1,6 +1,7 @@
 // evh_image.hip -- K0: area-average downscale, the MI355X counterpart of imutils.resize(frame, width=) ->
-// cv2.resize(INTER_AREA) at evenvizion/processing/video_processing.py:62,73.  Shrink only (the reference's
-// "resize_width to speed up" use); equal sizes are a plain copy.  Weights are float32 tables built on the host
+// cv2.resize(INTER_AREA) at evenvizion/processing/video_processing.py:62,73.  Shrinking (the reference's
+// "resize_width to speed up" use) = area sums; enlarging = the operator's bilinear emulation (k_resize_linear_area);
+// equal sizes are a plain copy.  Weights are float32 tables built on the host
 // exactly as the operator builds them; each output value is accumulated in float32 in table order
 // (inner sum over source columns, outer sum over source rows), then rounded half-to-even and saturated.
 #include "evh_internal.h"
@@ -116,6 +117,68 @@ __global__ __launch_bounds__(256) void k_ingest_area_int(const uint8_t* __restri
   pyr[(int64_t)img * pyr_frame_bytes + (int64_t)dy * dst_stride + dx] = cn == 3 ? gray_of(v[0], v[1], v[2]) : (uint8_t)v[0];
 }
 
+// INTER_AREA when ENLARGING (imutils.resize(frame, width=) with width > frame width, video_processing.py:62,73): the
+// operator emulates it with its 8-bit bilinear machinery -- 11-bit coefficients from area-mode tables
+//   s = floor(d*scale), f = (float)((d+1) - (s+1)*inv_scale), f = f <= 0 ? 0 : f - floor(f),
+// horizontal pass in int (x2048), vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.  One thread per
+// output pixel; the coefficients are recomputed per thread in the operator's own f64/f32 arithmetic.
+struct LinAreaCoef { int s; int a0, a1; };
+__device__ __forceinline__ LinAreaCoef lin_area_coef(int d, int ssize, double scale, double inv) {
+  int s = (int)floor((double)d * scale);
+  float f = (float)((double)(d + 1) - (double)(s + 1) * inv);
+  f = f <= 0.f ? 0.f : f - floorf(f);
+  if (s < 0) { f = 0.f; s = 0; }
+  bool edge = false;
+  if (s + 1 >= ssize) { edge = true; if (s >= ssize - 1) { f = 0.f; s = ssize - 1; } }
+  LinAreaCoef c;
+  c.s = s;
+  c.a0 = min(max((int)rintf((1.f - f) * 2048.f), -32768), 32767);
+  c.a1 = min(max((int)rintf(f * 2048.f), -32768), 32767);
+  if (edge) { c.a0 = 2048; c.a1 = 0; }           // D[dx] = S[sx] * ONE beyond xmax
+  return c;
+}
+__device__ __forceinline__ int lin_area_px(const uint8_t* S, int64_t stride, int cn, int c, int sw, int sh,
+                                           const LinAreaCoef& X, const LinAreaCoef& Y, int b0, int b1) {
+  const int y0 = min(Y.s, sh - 1), y1 = min(Y.s + 1, sh - 1);
+  const int x1 = min(X.s + 1, sw - 1);
+  const uint8_t* r0 = S + (int64_t)y0 * stride;
+  const uint8_t* r1 = S + (int64_t)y1 * stride;
+  const int h0 = r0[X.s * cn + c] * X.a0 + r0[x1 * cn + c] * X.a1;
+  const int h1 = r1[X.s * cn + c] * X.a0 + r1[x1 * cn + c] * X.a1;
+  return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+}
+// vertical coefficients: no edge substitution (the operator clips the ROWS instead)
+__device__ __forceinline__ void lin_area_beta(int dy, double scale, double inv, int& sy, int& b0, int& b1) {
+  sy = (int)floor((double)dy * scale);
+  float f = (float)((double)(dy + 1) - (double)(sy + 1) * inv);
+  f = f <= 0.f ? 0.f : f - floorf(f);
+  b0 = min(max((int)rintf((1.f - f) * 2048.f), -32768), 32767);
+  b1 = min(max((int)rintf(f * 2048.f), -32768), 32767);
+}
+template <bool INGEST>
+__global__ __launch_bounds__(256) void k_resize_linear_area(const uint8_t* __restrict__ src, int cn, int sw, int sh,
+                                                            int64_t src_stride, int64_t src_img_stride,
+                                                            uint8_t* __restrict__ dst, int dw, int dh, int64_t dst_stride,
+                                                            int64_t dst_img_stride, double scale_x, double inv_x,
+                                                            double scale_y, double inv_y) {
+  const int img = blockIdx.z, dy = blockIdx.y;
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dx >= dw) return;
+  const uint8_t* S = src + (int64_t)img * src_img_stride;
+  const LinAreaCoef X = lin_area_coef(dx, sw, scale_x, inv_x);
+  LinAreaCoef Y; int b0, b1;
+  lin_area_beta(dy, scale_y, inv_y, Y.s, b0, b1);
+  Y.s = min(max(Y.s, 0), sh - 1);
+  int v[3] = {0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; c++) if (c < cn) v[c] = lin_area_px(S, src_stride, cn, c, sw, sh, X, Y, b0, b1);
+  uint8_t* D = dst + (int64_t)img * dst_img_stride + (int64_t)dy * dst_stride;
+  if (INGEST) D[dx] = cn == 3 ? gray_of(v[0], v[1], v[2]) : (uint8_t)v[0];
+  else
+#pragma unroll
+    for (int c = 0; c < 3; c++) if (c < cn) D[dx * cn + c] = (uint8_t)v[c];
+}
+
 // N3: fixed-plane coordinate field of processing_visualization.py:407-408 -- every pixel (x, y) of
 // the resized frame mapped through the frame's superposed H -- and its maximum coordinate (the value
 // heatmap_video_processing returns and evenvizion_component.py writes to metrics_file.txt).
@@ -219,8 +282,13 @@ int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, i
   }
   const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
   const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
-  if (scale_x < 1 || scale_y < 1)
-    return evh_fail(c, EVH_ERR_UNSUPPORTED, "evh_resize_area_u8: enlarging is outside the hot path");
+  if (scale_x < 1 || scale_y < 1) {          // enlarging: the operator's bilinear emulation of INTER_AREA
+    hipLaunchKernelGGL(k_resize_linear_area<false>, dim3((dw + 255) / 256, dh, nimg), dim3(256), 0, c->stream, d_src, cn, sw,
+                       sh, src_stride, src_img_stride, d_dst, dw, dh, dst_stride, dst_img_stride, scale_x, inv_x, scale_y,
+                       inv_y);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
   dim3 grid((dw * cn + 255) / 256, dh, nimg);
   const int isx = (int)std::lrint(scale_x), isy = (int)std::lrint(scale_y);
   if (std::fabs(scale_x - isx) < 2.220446049250313e-16 && std::fabs(scale_y - isy) < 2.220446049250313e-16) {
@@ -290,20 +358,23 @@ static int area_tables(evh_ctx* c, int sw, int sh, int dw, int dh, double scale_
   return EVH_SUCCESS;
 }
 
-// level 0 of every frame straight from the full-size source (k_ingest_area*); enlarging is outside the hot path
+// level 0 of every frame straight from the source frames (k_ingest_area* when shrinking, k_resize_linear_area when enlarging)
 int evh_launch_ingest_level0(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
                              int64_t src_img_stride, int dw, int dh) {
   const EvhLevel& L = c->g.lv[0];
   const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
-  {
-    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;      // the operator's own arithmetic
-    if (1. / inv_x < 1 || 1. / inv_y < 1) return evh_fail(c, EVH_ERR_UNSUPPORTED, "ingest: enlarging is outside the hot path");
-  }
-  const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+  const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;      // the operator's own arithmetic
+  const double sx = 1. / inv_x, sy = 1. / inv_y;
   (void)scale_x; (void)scale_y;
   dim3 grid((dw + 255) / 256, dh, nimg);
-  const int isx = (int)std::lrint(sx), isy = (int)std::lrint(sy);
   c->level1_fused = false;
+  if (sx < 1 || sy < 1) {                    // enlarging: bilinear emulation, gray weights on the rounded channels
+    hipLaunchKernelGGL(k_resize_linear_area<true>, grid, dim3(256), 0, c->stream, d_src, cn, sw, sh, src_stride,
+                       src_img_stride, c->d_pyr + L.off, dw, dh, (int64_t)L.stride, c->g.pyr_frame_bytes, sx, inv_x, sy, inv_y);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
+  const int isx = (int)std::lrint(sx), isy = (int)std::lrint(sy);
   if (std::fabs(sx - isx) < 2.220446049250313e-16 && std::fabs(sy - isy) < 2.220446049250313e-16) {
     hipLaunchKernelGGL(k_ingest_area_int, grid, dim3(256), 0, c->stream, d_src, cn, src_stride, src_img_stride, c->d_pyr + L.off,
                        c->g.pyr_frame_bytes, dw, dh, L.stride, isx, isy);

@@ -94,6 +94,8 @@ struct evh_ctx {
   float* d_crow = nullptr;        // [max_pairs][kcap][4] compacted inlier rows
   int* d_info = nullptr;          // [max_pairs][8]
   double* d_small = nullptr;      // small staging area for single-problem entries (H, counts)
+  char* d_scratch = nullptr;      // growable scratch of the host-pointer entries (N1 / N3): no hipMalloc per call
+  size_t scratch_bytes = 0;
   size_t bytes_allocated = 0;
   std::string err;
   // per-stage timing (evh_profile_*)

@@ -1564,18 +1564,25 @@ int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A_, int npairs, int
   unsigned long long* d_prof = nullptr;
   if (want_prof) {
     EVH_HIP(c, hipMalloc(&d_prof, sizeof(unsigned long long) * PF_NSLOTS));
-    EVH_HIP(c, hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * PF_NSLOTS, c->stream));
+    if (hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * PF_NSLOTS, c->stream) != hipSuccess) {
+      (void)hipFree(d_prof);
+      return evh_fail(c, EVH_ERR_HIP, "EVH_RANSAC_PROF: hipMemsetAsync failed");
+    }
     A.prof = d_prof;
   }
   // nstreams == 0: independent pairs; otherwise nstreams sequential scans of npairs pairs each, `pitch` pair slots apart
   if (nstreams > 0) EVH_LAUNCH_NW(waves_for(nstreams, A.force_max), k_ransac_final_stream, nstreams, c->stream, A, npairs, pitch);
   else EVH_LAUNCH_NW(waves_for(npairs, A.force_max), k_ransac_final_pairs, npairs, c->stream, A);
-  EVH_HIP(c, hipGetLastError());
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { if (d_prof) (void)hipFree(d_prof); return evh_fail(c, EVH_ERR_HIP, std::string("k_ransac_final: ") + hipGetErrorString(le)); }
+  }
   if (d_prof) {
     unsigned long long h[PF_NSLOTS];
-    EVH_HIP(c, hipStreamSynchronize(c->stream));
-    EVH_HIP(c, hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
-    (void)hipFree(d_prof);
+    hipError_t pe = hipStreamSynchronize(c->stream);
+    if (pe == hipSuccess) pe = hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d_prof);                       // released on every path
+    if (pe != hipSuccess) return evh_fail(c, EVH_ERR_HIP, std::string("EVH_RANSAC_PROF read-back: ") + hipGetErrorString(pe));
     const double n = h[PF_CALLS] ? (double)h[PF_CALLS] : 1.0;
     fprintf(stderr, "[evh ransac_final prof] calls %llu | per call (cycles): total %.0f hyp %.0f (chunks %.2f, dlt4+jacobi %.0f) "
             "compact %.0f refit %.0f lm %.0f (iters %.2f, solve8 %.0f, eval %.0f) | rotations: 9x9 %.1f 8x8 %.1f | chunk loop: rng %.0f "

@@ -14,14 +14,17 @@ from .. import runtime
 
 def _convert(coordinates, homography_dict, kx, ky, inverse):
     frames = list(coordinates.keys())
-    mats = [np.asarray(homography_dict[f], np.float64) for f in frames]
-    if inverse:
-        mats = [linalg.inv(m) for m in mats]
-    pts, idx = [], []
-    for i, f in enumerate(frames):
+    # like the reference, a frame's matrix is only touched (looked up, inverted) when the frame has a point to map
+    # (fixed_coordinate_system.py:56-69): an empty frame may have no H entry or a singular one
+    mats, pts, idx = [], [], []
+    for f in frames:
+        if not coordinates[f]:
+            continue
+        m = np.asarray(homography_dict[f], np.float64)
+        mats.append(linalg.inv(m) if inverse else m)
         for rect in coordinates[f]:
             pts.append((rect["x1"], rect["y1"]))
-            idx.append(i)
+            idx.append(len(mats) - 1)
     out = (runtime.get_context(64, 64, 2, runtime.NFEATURES).transform_points(mats, idx, pts, kx, ky, decimals=2)
            if pts else np.zeros((0, 2)))
     result, k = {}, 0

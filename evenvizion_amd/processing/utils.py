@@ -38,21 +38,29 @@ def _small_context():
     return runtime.get_context(64, 64, 2, runtime.NFEATURES)
 
 
-def _as_xy(vector):
+def _transform(vector, matrix):
     v = np.asarray(vector, np.float64).reshape(-1)
-    if len(v) > 2 and v[2] != 1:
-        raise NotImplementedError("homogeneous input with w != 1 is outside the hot path")
-    return v[:2]
+    while len(v) < 3:
+        v = np.append(v, [1])
+    if v[2] != 1:
+        # a homogeneous vector whose last coordinate is not 1: the reference multiplies it as it stands and divides by
+        # the result's last coordinate (utils.py:89-92).  The batched device transform takes (x, y, 1) points only, so
+        # this rare form stays the reference's two numpy operations on the host (pure glue, no frame data).
+        new_vector = np.dot(np.asarray(matrix, np.float64), v)
+        return new_vector[:-1] / new_vector[-1]
+    return _small_context().transform_points(matrix, [0], [v[:2]])[0]
 
 
 def homography_transformation(vector, matrix_H):
-    """(x, y[, 1]) -> np.dot(H, (x, y, 1))[:2] / [2] as float64[2] (utils.py:89-92), on the device."""
-    return _small_context().transform_points(matrix_H, [0], [_as_xy(vector)])[0]
+    """(x, y[, w]) -> np.dot(H, (x, y, w))[:2] / [2] as float64[2] (utils.py:89-92); w defaults to 1.  One point per call
+    costs a device round trip: callers with many points should use Context.transform_points (as
+    fixed_coordinate_system and the heat-map do) instead of np.apply_along_axis over this function."""
+    return _transform(vector, matrix_H)
 
 
 def inverse_homography_transformation(vector, matrix_H):
     """The same through numpy.linalg.inv(H) (utils.py:112-115)."""
-    return _small_context().transform_points(linalg.inv(np.asarray(matrix_H, np.float64)), [0], [_as_xy(vector)])[0]
+    return _transform(vector, linalg.inv(np.asarray(matrix_H, np.float64)))
 
 
 def matrix_superposition(H, matrix_H_superposition, matrix_H_first=False):
@@ -79,10 +87,15 @@ def superposition_dict(homography_dict):
     """{1: identity, frame_no: running superposition of the per-frame H} (utils.py:203-211): one device scan."""
     superposition_homography_dict = {1: [[1, 0, 0], [0, 1, 0], [0, 0, 1]]}
     frames = list(homography_dict.keys())
-    if frames:
-        sup = _small_context().superposition_scan([homography_dict[k]["H"] for k in frames])
-        for k, m in zip(frames, sup):
-            superposition_homography_dict[k] = m
+    # a None H keeps the running superposition unchanged (matrix_superposition returns H_sup for H None, utils.py:139):
+    # such frames are left out of the device scan and take the previous frame's matrix afterwards
+    live = [k for k in frames if homography_dict[k]["H"] is not None]
+    sup = _small_context().superposition_scan([homography_dict[k]["H"] for k in live]) if live else []
+    by_frame = dict(zip(live, sup))
+    prev = None
+    for k in frames:
+        prev = by_frame.get(k, prev)
+        superposition_homography_dict[k] = prev
     return superposition_homography_dict
 
 

@@ -40,9 +40,8 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     h0, w0 = first.shape[:2]
     cn = 1 if first.ndim == 2 else first.shape[2]
     dw, dh = resized_shape(first.shape, resize_width)
-    if dw > w0 or dh > h0:
-        raise NotImplementedError("resize_width larger than the frame (INTER_AREA enlargement) is outside the hot path")
-    chunk_frames = max(2, int(chunk_frames))
+    # one staging buffer (pinned host / device) is capped in bytes: 4K BGR frames give 21-frame chunks, not 64
+    chunk_frames = runtime.chunk_frames_for(first.nbytes, max(2, int(chunk_frames)))
     # sized for the RESIZED frames: only those go through ORB (evh_resize_area_u8 does not depend on the context's
     # geometry), so a 4K source with resize_width=400 allocates 400-wide buffers
     ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures)
@@ -55,25 +54,71 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     H_dev, st_dev, H_host, st_host = B["H_dev"], B["st_dev"], B["H_host"], B["st_host"]
     copy_stream, up_done, all_done = B["copy_stream"], B["up_done"], B["all_done"]
     state = torch.zeros(18, dtype=torch.float64, device=dev)
+    # {H_sup, H_prev} as they ENTER each in-flight chunk (and whether there was a state at all): what a chunk is re-run
+    # from when one of its frames overflows a frame slot (EVH_PAIR_CAPACITY)
+    state_pre = [torch.zeros(18, dtype=torch.float64, device=dev) for _ in range(2)]
+    had_state = [False, False]
     cuda = dev.type == "cuda"          # (the host-loop unit test drives this function on the CPU with a scripted context)
     cur = torch.cuda.current_stream(dev) if cuda else None
 
     homography_dict = {}
     frame_no = [1]          # 1-based index of the newest frame already paired
 
-    def collect(jb, nb):
+    def launch(c, jb, nb, with_state):
+        c.stream_homography_batch(devbuf[jb][:nb], H_dev[jb], st_dev[jb], state_in=state if with_state else None,
+                                  state_out=state, nfeatures=nfeatures, resize_to=(dw, dh))
+        if cuda:
+            c.order_torch_after()
+        H_host[jb][:nb - 1].copy_(H_dev[jb][:nb - 1], non_blocking=True)
+        st_host[jb][:nb - 1].copy_(st_dev[jb][:nb - 1], non_blocking=True)
+        if cuda:
+            all_done[jb].record(cur)
+
+    def rerun_with_larger_slots(jb, nb, later):
+        """A frame of chunk jb delivered more tied key points than a frame slot of `ctx` holds.  The reference has no
+        such bound (it carries on with every tie, frame_processing.py:59-61), so the chunk is re-run from the state it
+        was entered with on a context whose frame slots are twice as large (same nfeatures, so the same key points for
+        every other frame), doubling again if needed up to the LDS limit of the matching filter; the chunk launched
+        after it (computed from a state that is now stale) is then re-run as well."""
+        from .._lib import Context
+        if cuda:
+            torch.cuda.synchronize(dev)
+        feats = max(ctx.max_features, nfeatures)
+        while True:
+            feats *= 2
+            try:
+                big = Context(device=runtime.device_index(), max_w=max(dw, 64), max_h=max(dh, 64), max_features=feats,
+                              max_frames=chunk_frames)
+            except EvhError:
+                raise EvhError("frame %d..%d: more tied key points than the largest frame slot this device path "
+                               "supports" % (frame_no[0], frame_no[0] + nb - 1))
+            try:
+                state.copy_(state_pre[jb])
+                launch(big, jb, nb, had_state[jb])
+                if cuda:
+                    torch.cuda.synchronize(dev)
+                else:
+                    big.synchronize()
+            finally:
+                big.close()
+            if not (st_host[jb][:nb - 1].numpy() == PAIR_CAPACITY).any():
+                break
+        if later is not None:                           # the chunk that was in flight behind it
+            lj, ln = later
+            state_pre[lj].copy_(state)
+            had_state[lj] = True
+            launch(ctx, lj, ln, True)
+
+    def collect(jb, nb, later=None):
         if cuda:
             all_done[jb].synchronize()
+        if (st_host[jb][:nb - 1].numpy() == PAIR_CAPACITY).any():
+            rerun_with_larger_slots(jb, nb, later)
         Hs = H_host[jb][:nb - 1].numpy().reshape(-1, 3, 3)
         sts = st_host[jb][:nb - 1].numpy()
         for k in range(nb - 1):
             frame_no[0] += 1
             fno = frame_no[0]
-            if sts[k] == PAIR_CAPACITY:
-                # not a "no homography" outcome of the reference: a frame delivered more tied key points than a frame
-                # slot holds (see include/evhip.h, EVH_PAIR_CAPACITY) -- repeating H_prev would hide a wrong result
-                raise EvhError("frame %d or %d holds more key points (ties at the retainBest cut) than a frame slot "
-                               "of this context; raise nfeatures capacity" % (fno - 1, fno))
             if sts[k] != PAIR_OK:
                 logging.info("pair ending at frame %d: no homography (status %d)", fno, int(sts[k]))
                 if not none_H_processing or not np.all(np.isfinite(Hs[k])):
@@ -111,18 +156,13 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
                     devbuf[j][:n].copy_(host[j][:n])
                 # K0 fused into the ingest kernel: level 0 comes straight from the full-size frames (N2); equal sizes
                 # are the plain gray conversion
-                ctx.stream_homography_batch(devbuf[j][:n], H_dev[j], st_dev[j], state_in=state if have_state else None,
-                                            state_out=state, nfeatures=nfeatures, resize_to=(dw, dh))
-                if cuda:
-                    ctx.order_torch_after()
-                H_host[j][:n - 1].copy_(H_dev[j][:n - 1], non_blocking=True)
-                st_host[j][:n - 1].copy_(st_dev[j][:n - 1], non_blocking=True)
-                if cuda:
-                    all_done[j].record(cur)
+                state_pre[j].copy_(state)               # stream-ordered: after chunk i-1's kernels, before chunk i's
+                had_state[j] = have_state
+                launch(ctx, j, n, have_state)
                 have_state = True
                 launched = (j, n)
             if inflight is not None:
-                collect(*inflight)
+                collect(*inflight, later=launched)
             inflight = launched
             if inflight is None:
                 break
@@ -131,5 +171,6 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     finally:
         if cuda:
             torch.cuda.synchronize(dev)                 # nothing of this call is left in flight on the shared buffers
+        runtime.release_staging()                       # nothing stays pinned / resident between videos
     homography_dict["resize_info"] = {"h": dh, "w": dw}
     return homography_dict

@@ -45,18 +45,33 @@ def to_device(array):
 
 
 _staging = {}
+STAGING_BYTES_PER_BUFFER = 512 << 20   # cap of one pinned / device chunk buffer of get_homography_dict
+
+
+def chunk_frames_for(frame_bytes, wanted):
+    """Frames per chunk so that one staging buffer stays within STAGING_BYTES_PER_BUFFER (at least 2 frames: 4K BGR =
+    24.9 MB per frame -> 21 frames per chunk instead of 64)."""
+    return max(2, min(int(wanted), STAGING_BYTES_PER_BUFFER // max(int(frame_bytes), 1)))
+
+
+def _pin(t):
+    try:
+        return t.pin_memory()
+    except RuntimeError:                   # small hosts / locked-memory limits: pageable staging still works, only slower
+        return t
 
 
 def staging(shape, dev):
     """Two pinned host chunks, two device chunks, result buffers, a copy stream and events for the chunk pipeline of
-    get_homography_dict; cached per chunk shape (pinning GBs of host memory is not free)."""
+    get_homography_dict; cached per chunk shape while a video is being processed and dropped by release_staging()
+    (called at the end of get_homography_dict: nothing stays pinned or resident between videos)."""
     import torch
     key = (tuple(shape), str(dev))
     if key not in _staging:
         _staging.clear()                      # one shape at a time: a new video size replaces the old buffers
         npairs = shape[0] - 1
         cuda = torch.device(dev).type == "cuda"
-        pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
+        pin = _pin if cuda else (lambda t: t)
         host = [pin(torch.empty(shape, dtype=torch.uint8)) for _ in range(2)]
         _staging[key] = {
             "host": host, "host_np": [t.numpy() for t in host],
@@ -70,6 +85,10 @@ def staging(shape, dev):
             "all_done": [torch.cuda.Event() for _ in range(2)] if cuda else None,
         }
     return _staging[key]
+
+
+def release_staging():
+    _staging.clear()
 
 
 def reset():

@@ -112,6 +112,29 @@ def make_stream(seed, nframes, w, h, noise=2.0):
     return frames, Hs
 
 
+def make_pan_stream(seed, nframes, w, h, step=4.0, noise=2.0):
+    """A long monotone pan: frame k views a (w + nframes*step + 2*MARGIN)-wide canvas at x-offset k*step (plus a small
+    random jitter in rotation / y), so the running superposition H_sup translates by about nframes*step pixels --
+    the long-stream regime of BASELINE configs[2] (utils.py:351-355: points are pre-transformed by H_sup, far from the
+    origin, before the fp32 cast inside findHomography).  -> frames u8[F,h,w]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W = int(w + nframes * step) + 2 * MARGIN + 8
+    Hc = h + 2 * MARGIN
+    acc = np.full((Hc, W), 128, np.int32)
+    for c in (4, 8, 16, 32):
+        gh, gw = -(-Hc // c), -(-W // c)
+        g = rng.integers(-40, 41, size=(gh, gw), dtype=np.int32)
+        acc += np.repeat(np.repeat(g, c, axis=0), c, axis=1)[:Hc, :W]
+    canvas = np.clip(acc, 0, 255).astype(np.uint8)
+    frames = np.empty((nframes, h, w), np.uint8)
+    for k in range(nframes):
+        th = np.deg2rad(rng.uniform(-0.4, 0.4))
+        G = np.array([[np.cos(th), -np.sin(th), k * step + rng.uniform(-0.5, 0.5)],
+                      [np.sin(th), np.cos(th), rng.uniform(-2, 2)], [0, 0, 1]], np.float64)
+        frames[k] = warp_canvas(canvas, G, w, h, rng, noise)
+    return frames
+
+
 def gray_to_bgr(gray):
     return np.repeat(gray[..., None], 3, axis=-1)
 

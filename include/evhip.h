@@ -83,7 +83,8 @@ int evh_profile_enable(evh_ctx* ctx, int on);
 int evh_profile_read(evh_ctx* ctx, float* h_total_ms /*[EVH_NSTAGES]*/, int* h_counts /*[EVH_NSTAGES]*/);
 const char* evh_profile_stage_name(int stage);
 
-/* ---- K0: imutils.resize -> cv2.resize(INTER_AREA), shrink only (identity = copy) --------------------------- */
+/* ---- K0: imutils.resize -> cv2.resize(INTER_AREA): area sums when shrinking, the operator's bilinear emulation
+ * when enlarging (resize_width > frame width), identity = copy ------------------------------------------------- */
 /* nimg images of sh x sw x cn uint8 (row stride src_stride bytes, image stride src_img_stride bytes).          */
 int evh_resize_area_u8(evh_ctx* ctx, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
                        int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
@@ -137,7 +138,8 @@ int evh_orb_count(evh_ctx* ctx, int frame);
 /* N2, fused ingest: the same detect on frames of src_w x src_h that the reference would first shrink with
  * imutils.resize(frame, width=w) (video_processing.py:62,73): level 0 is produced straight from the full-size frame
  * (INTER_AREA per channel, rounded to uint8 as the resized image would be, then the gray weights) -- the resized BGR
- * image is never materialised.  (w, h) is the working size: h = int(src_h * (w / float(src_w))).  Shrinking only.   */
+ * image is never materialised.  (w, h) is the working size: h = int(src_h * (w / float(src_w))); it may
+ * also be LARGER than the source (resize_width > frame width: INTER_AREA's bilinear emulation).                       */
 int evh_orb_detect_batch_resized(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
                                  int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures);
 int evh_orb_capacity(const evh_ctx* ctx);

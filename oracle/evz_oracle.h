@@ -34,7 +34,7 @@ enum {
 
 /* ---- K1 / K0: colour + resize (frame_processing.py:61 -> cvtColor; video_processing.py:62,73) ---- */
 void evo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray);
-/* imutils.resize(width=) -> cv2.resize(INTER_AREA); returns 0 ok, -1 unsupported (upscale) */
+/* imutils.resize(width=) -> cv2.resize(INTER_AREA): area sums (shrink) or the bilinear emulation (enlarge); returns 0 */
 int evo_resize_area(const uint8_t* src, int sw, int sh, int cn, uint8_t* dst, int dw, int dh);
 void evo_resize_linear_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
 

@@ -49,7 +49,8 @@ extern "C" void evo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8
 }
 
 /* ------------------------------------------------------------------------------------------------ */
-/* cv2.resize(..., INTER_AREA) for shrinking (imutils.resize, video_processing.py:62,73)               */
+/* cv2.resize(..., INTER_AREA) (imutils.resize, video_processing.py:62,73): area sums when shrinking, the    */
+/* bilinear emulation when enlarging                                                                   */
 namespace {
 struct DecAlpha { int si, di; float alpha; };
 void area_tab(int ssize, int dsize, double scale, std::vector<DecAlpha>& tab) {
@@ -71,7 +72,52 @@ extern "C" int evo_resize_area(const uint8_t* src, int sw, int sh, int cn, uint8
   if (dw == sw && dh == sh) { memcpy(dst, src, (size_t)sw * sh * cn); return 0; }
   double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
   double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
-  if (scale_x < 1 || scale_y < 1) return -1;  // enlarging with INTER_AREA: not on the hot path
+  if (scale_x < 1 || scale_y < 1) {
+    // "true area interpolation is only implemented for scale_x >= 1 && scale_y >= 1; in other cases it is emulated
+    // using some variant of bilinear interpolation" (imgproc resize): INTER_AREA then runs the 8-bit INTER_LINEAR
+    // machinery (11-bit coefficients, HResizeLinear / VResizeLinear) with area-mode coefficient tables:
+    //   sx = floor(dx*scale), fx = (float)((dx+1) - (sx+1)*inv_scale), fx = fx <= 0 ? 0 : fx - floor(fx).
+    // Reached by imutils.resize(frame, width=) with width > frame width (video_processing.py:62,73).
+    std::vector<int> xo(dw), yo(dh);
+    std::vector<short> xa(2 * (size_t)dw), ya(2 * (size_t)dh);
+    auto tab = [](int ssize, int dsize, double scale, double inv, int* ofs, short* al, int& vmax) {
+      vmax = dsize;
+      for (int d = 0; d < dsize; d++) {
+        int s = floor_d(d * scale);
+        float f = (float)((d + 1) - (s + 1) * inv);
+        f = f <= 0 ? 0.f : f - (float)floor_d((double)f);
+        if (s < 0) { f = 0; s = 0; }
+        if (s + 1 >= ssize) { vmax = std::min(vmax, d); if (s >= ssize - 1) { f = 0; s = ssize - 1; } }
+        ofs[d] = s;
+        const float c0 = 1.f - f, c1 = f;
+        auto sat = [](float v) { int i = round_f(v); return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i); };
+        al[2 * d] = sat(c0 * 2048); al[2 * d + 1] = sat(c1 * 2048);
+      }
+    };
+    int xmax, ymax;
+    tab(sw, dw, scale_x, inv_x, xo.data(), xa.data(), xmax);
+    tab(sh, dh, scale_y, inv_y, yo.data(), ya.data(), ymax);
+    (void)ymax;
+    std::vector<int> r0((size_t)dw * cn), r1((size_t)dw * cn);
+    auto hrow = [&](int sy, std::vector<int>& D) {
+      const uint8_t* S = src + (size_t)sy * sw * cn;
+      for (int dx = 0; dx < dw; dx++)
+        for (int c = 0; c < cn; c++) {
+          const int sx = xo[dx];
+          D[dx * cn + c] = dx < xmax ? S[sx * cn + c] * xa[2 * dx] + S[(sx + 1) * cn + c] * xa[2 * dx + 1]
+                                     : S[sx * cn + c] * 2048;
+        }
+    };
+    auto clip = [](int v, int a, int b) { return v >= a ? (v < b ? v : b - 1) : a; };
+    for (int dy = 0; dy < dh; dy++) {
+      hrow(clip(yo[dy], 0, sh), r0);
+      hrow(clip(yo[dy] + 1, 0, sh), r1);
+      const int b0 = ya[2 * dy], b1 = ya[2 * dy + 1];
+      uint8_t* D = dst + (size_t)dy * dw * cn;
+      for (int i = 0; i < dw * cn; i++) D[i] = (uint8_t)((((b0 * (r0[i] >> 4)) >> 16) + ((b1 * (r1[i] >> 4)) >> 16) + 2) >> 2);
+    }
+    return 0;
+  }
   int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
   bool fast = std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON;
   if (fast) {

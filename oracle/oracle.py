@@ -69,8 +69,7 @@ def resize_area(img, dw, dh):
     sh, sw = img.shape[:2]
     out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
     rc = lib().evo_resize_area(_p(img), sw, sh, cn, _p(out), dw, dh)
-    if rc != 0:
-        raise NotImplementedError("INTER_AREA enlargement is outside the hot path")
+    assert rc == 0
     return out
 
 

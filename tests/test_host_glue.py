@@ -170,3 +170,74 @@ def test_driver_loop_matches_reference(goldens, monkeypatch, chunk):
         video_processing.get_homography_dict(_Cap(0))
     with pytest.raises(NotImplementedError):
         video_processing.get_homography_dict(_Cap(3), matching_path="/tmp/x")
+
+
+def test_install_as_evenvizion_keeps_the_real_package_reachable(tmp_path, monkeypatch):
+    """evenvizion_amd.install_as_evenvizion(): the five imports of evenvizion/examples/evenvizion_component.py:30-35
+    work afterwards -- the processing modules resolve to this implementation, `evenvizion.visualization.*` (out of scope
+    here) still resolves to the real package's own files, found through its search path WITHOUT running its __init__
+    (which would import every example script).  The stand-in package below has the reference's layout; when
+    /root/reference is present (build container only) the same is done against the real files with cv2 / imutils
+    replaced by inert stubs."""
+    import importlib
+    import sys
+    import types
+    import evenvizion_amd
+
+    def run(package_parent):
+        saved = {k: v for k, v in sys.modules.items() if k == "evenvizion" or k.startswith("evenvizion.")}
+        for k in saved:
+            del sys.modules[k]
+        sys.path.insert(0, str(package_parent))
+        try:
+            pkg = evenvizion_amd.install_as_evenvizion()
+            from evenvizion.processing.fixed_coordinate_system import from_original_to_fix
+            from evenvizion.processing.utils import read_homography_dict, superposition_dict, \
+                are_infinity_coordinates, read_json_with_coordinates
+            from evenvizion.processing.video_processing import get_homography_dict
+            from evenvizion.visualization.processing_visualization import \
+                heatmap_video_processing, comparison_original_with_fixed_coordinate_video_processing
+            assert get_homography_dict is video_processing.get_homography_dict
+            assert from_original_to_fix.__module__ == "evenvizion_amd.processing.fixed_coordinate_system"
+            assert read_homography_dict is utils.read_homography_dict and superposition_dict is utils.superposition_dict
+            assert are_infinity_coordinates is utils.are_infinity_coordinates and callable(read_json_with_coordinates)
+            assert callable(heatmap_video_processing) and callable(comparison_original_with_fixed_coordinate_video_processing)
+            assert sys.modules["evenvizion.processing"] is pkg
+            viz = sys.modules["evenvizion.visualization.processing_visualization"]
+            assert viz.__file__.startswith(str(package_parent))
+            # the visualisation module found THIS implementation's helpers underneath
+            assert viz.homography_transformation is utils.homography_transformation
+        finally:
+            sys.path.remove(str(package_parent))
+            for k in [k for k in sys.modules if k == "evenvizion" or k.startswith("evenvizion.")]:
+                del sys.modules[k]
+            sys.modules.update(saved)
+
+    root = tmp_path / "site"
+    (root / "evenvizion" / "visualization").mkdir(parents=True)
+    (root / "evenvizion" / "__init__.py").write_text("raise ImportError('the package __init__ must not be executed')\n")
+    (root / "evenvizion" / "visualization" / "__init__.py").write_text("")
+    (root / "evenvizion" / "visualization" / "processing_visualization.py").write_text(
+        "from evenvizion.processing.constants import HEATMAP_CONSTANT\n"
+        "from evenvizion.processing.utils import are_infinity_coordinates, homography_transformation\n"
+        "def heatmap_video_processing(*a, **k):\n    return HEATMAP_CONSTANT\n"
+        "def comparison_original_with_fixed_coordinate_video_processing(*a, **k):\n    return None\n")
+    run(root)
+    if os.path.isdir("/root/reference/evenvizion"):
+        for name in ("cv2", "imutils"):
+            if name not in sys.modules:
+                monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+        run("/root/reference")
+    importlib.invalidate_caches()
+
+
+def test_homogeneous_vector_with_w_not_one_follows_the_reference():
+    """utils.homography_transformation(vector, H) with a 3-vector whose last coordinate is not 1 (utils.py:86-92): the
+    reference multiplies it as it stands.  Host glue, no device involved."""
+    H = np.array([[1.1, 0.02, 3.0], [-0.01, 0.97, -2.0], [1e-4, -2e-4, 1.0]])
+    v = np.array([10.0, 20.0, 2.0])
+    want = np.dot(H, v)
+    got = utils.homography_transformation(v, H)
+    assert np.array_equal(got, want[:-1] / want[-1])
+    wi = np.dot(np.linalg.inv(H), v)
+    assert np.array_equal(utils.inverse_homography_transformation(v, H), wi[:-1] / wi[-1])

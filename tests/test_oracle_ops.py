@@ -99,8 +99,15 @@ def test_area_resize_properties():
     assert np.abs(q - want).max() <= 0.5 + 1e-9
     g = O.resize_area(np.full((658, 1170), 201, np.uint8), 400, 224)                     # the reference's geometry
     assert g.shape == (224, 400) and (g == 201).all()
-    with pytest.raises(NotImplementedError):
-        O.resize_area(img, 160, 120)
+    # enlarging (resize_width > frame width): INTER_AREA's bilinear emulation.  Definitions: a constant image stays
+    # constant; an exact 2x enlargement duplicates every sample (area-mode coefficients: fx = 0 for both copies)
+    up = O.resize_area(np.full((45, 80, 3), 77, np.uint8), 400, 225)
+    assert up.shape == (225, 400, 3) and (up == 77).all()
+    up2 = O.resize_area(img, 160, 120)
+    assert np.array_equal(up2, np.repeat(np.repeat(img, 2, axis=0), 2, axis=1))
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8), (10, 1))                          # 100 wide, slope 2
+    r = O.resize_area(ramp, 150, 15).astype(int)                                           # x1.5: monotone, within range
+    assert (np.diff(r, axis=1) >= 0).all() and r.min() == 0 and r.max() == 198 and (r[0] == r[-1]).all()
 
 
 def test_gaussian_blur_kernel():
