@@ -65,7 +65,21 @@ SIGNATURES = {
     "evh_pair_from_slots": (_i, [_vp, _i, _i, _vp, _vp, _pi]),
     "evh_match_static_from_slots": (_i, [_vp, _i, _i, _vp, _i, _pi, _pi]),
     "evh_compute_homography": (_i, [_vp, _vp, _i, _vp, _vp, _pi]),
+    # N4: SIFT + multi-type pairs
+    "evh_sift_enable": (_i, [_vp, _i]),
+    "evh_sift_capacity": (_i, [_vp]),
+    "evh_sift_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i]),
+    "evh_sift_count": (_i, [_vp, _i]),
+    "evh_sift_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evh_sift_octave_info": (_i, [_vp, _i, _pi, _pi]),
+    "evh_sift_download_gauss": (_i, [_vp, _i, _i, _i, _vp]),
+    "evh_match_knn2_l2f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "evh_ratio_unique_filter_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _i, _vp, _pi, _pi]),
+    "evh_pair_homography_batch_types": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _vp, _i, _d, _i, _d, _i, _vp, _vp]),
+    "evh_stream_homography_batch_types": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _vp, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
 }
+FEATURE_ORB, FEATURE_SIFT, FEATURE_SURF = 0, 1, 2
+FEATURE_CODES = {"ORB": FEATURE_ORB, "SIFT": FEATURE_SIFT, "SURF": FEATURE_SURF}
 
 
 class EvhError(RuntimeError):
@@ -342,6 +356,86 @@ class Context:
         self._check(self.lib.evh_multi_stream_homography_batch(
             self.h, frames.data_ptr(), S, F, w, h, cn, w * cn, w * h * cn, nfeatures, float(thr), int(max_iters),
             float(conf), int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,
+            state_out.data_ptr() if state_out is not None else None, out_H.data_ptr(), out_status.data_ptr()))
+
+    # ---- N4: SIFT + multi-type pairs ----
+    def sift_enable(self, max_sift_features=8192):
+        self._check(self.lib.evh_sift_enable(self.h, int(max_sift_features)))
+
+    def sift_detect_batch(self, frames, resize_to=None):
+        """frames: CUDA uint8 [n,h,w] or [n,h,w,3]; SIFT_create().detectAndCompute on each (frame_processing.py:62-64)."""
+        self._enter()
+        n, h, w = frames.shape[:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        dw, dh = (w, h) if resize_to is None else (int(resize_to[0]), int(resize_to[1]))
+        self._check(self.lib.evh_sift_detect_batch(self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, dw, dh))
+
+    def sift_download(self, frame):
+        cap = self.lib.evh_sift_capacity(self.h)
+        xy = np.zeros((cap, 2), np.float32); desc = np.zeros((cap, 128), np.float32); oc = np.zeros(cap, np.int32)
+        sz = np.zeros(cap, np.float32); an = np.zeros(cap, np.float32); rs = np.zeros(cap, np.float32)
+        n = self._check(self.lib.evh_sift_download(self.h, frame, _hp(xy), _hp(desc), _hp(oc), _hp(sz), _hp(an), _hp(rs)))
+        return dict(xy=xy[:n].copy(), desc=desc[:n].copy(), octave=oc[:n].copy(), size=sz[:n].copy(), angle=an[:n].copy(),
+                    response=rs[:n].copy())
+
+    def sift_octaves(self):
+        out = []
+        while True:
+            w = C.c_int(); h = C.c_int()
+            rc = self.lib.evh_sift_octave_info(self.h, len(out), C.byref(w), C.byref(h))
+            if rc != 0:
+                break
+            out.append((w.value, h.value))
+        return out
+
+    def sift_download_gauss(self, frame, octave, layer):
+        w, h = self.sift_octaves()[octave]
+        out = np.zeros((h, w), np.float32)
+        self._check(self.lib.evh_sift_download_gauss(self.h, frame, octave, layer, _hp(out)))
+        return out
+
+    def knn2_f32(self, q, t, idx, dist):
+        """q, t: CUDA float32 [n,dim] (dim 64 or 128); idx int32 [nq,2], dist float32 [nq,2]."""
+        self._enter()
+        self._check(self.lib.evh_match_knn2_l2f32(self.h, q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0], q.shape[1],
+                                                  idx.data_ptr(), dist.data_ptr()))
+
+    def ratio_unique_filter_f32(self, idx, dist, xy_q, xy_t, pts, ratio=0.5, min_matches=4):
+        self._enter()
+        n = C.c_int(); st = C.c_int()
+        self._check(self.lib.evh_ratio_unique_filter_f32(self.h, idx.data_ptr(), dist.data_ptr(), idx.shape[0], xy_t.shape[0],
+                                                         xy_q.data_ptr(), xy_t.data_ptr(), float(ratio), int(min_matches),
+                                                         pts.data_ptr(), C.byref(n), C.byref(st)))
+        return n.value, st.value
+
+    @staticmethod
+    def _types(features):
+        codes = np.ascontiguousarray([FEATURE_CODES[f] if isinstance(f, str) else int(f) for f in features], np.int32)
+        return codes
+
+    def pair_homography_batch_types(self, frames, npairs, mode, out_H, out_status, features, nfeatures=500, thr=3.0,
+                                    max_iters=2000, conf=0.995, force_max_iters=False, resize_to=None):
+        self._enter()
+        h, w = frames.shape[1:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        dw, dh = (w, h) if resize_to is None else (int(resize_to[0]), int(resize_to[1]))
+        t = self._types(features)
+        self._check(self.lib.evh_pair_homography_batch_types(
+            self.h, frames.data_ptr(), npairs, mode, w, h, cn, w * cn, w * h * cn, dw, dh, nfeatures, _hp(t), len(t), float(thr),
+            int(max_iters), float(conf), int(bool(force_max_iters)), out_H.data_ptr(), out_status.data_ptr()))
+
+    def stream_homography_batch_types(self, frames, out_H, out_status, features, state_in=None, state_out=None, nfeatures=500,
+                                      thr=3.0, max_iters=2000, conf=0.995, force_max_iters=False, resize_to=None):
+        """stream_homography_batch with a list of feature types ("SIFT", "ORB", ... in the order the reference's
+        FrameProcessing would loop over them, frame_processing.py:91-104)."""
+        self._enter()
+        n, h, w = frames.shape[:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        dw, dh = (w, h) if resize_to is None else (int(resize_to[0]), int(resize_to[1]))
+        t = self._types(features)
+        self._check(self.lib.evh_stream_homography_batch_types(
+            self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, dw, dh, nfeatures, _hp(t), len(t), float(thr),
+            int(max_iters), float(conf), int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,
             state_out.data_ptr() if state_out is not None else None, out_H.data_ptr(), out_status.data_ptr()))
 
     def _torch_stream(self):

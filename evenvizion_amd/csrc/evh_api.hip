@@ -224,6 +224,161 @@ int solve_pairs(evh_ctx* c, EvhRansacArgs R, int npairs, int nstreams = 0, int p
   return rc;
 }
 
+
+// level 0 (gray) of every frame: (sw, sh) = size of the frames handed over, (w, h) = working size.  Different sizes =
+// fused ingest (N2).  Shared by every feature type of a call.
+int ingest_level0(evh_ctx* c, const char* who, const uint8_t* d_frames, int nframes, int sw, int sh, int w, int h,
+                         int channels, int64_t row_stride, int64_t frame_stride, int nfeatures) {
+  if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": NULL argument");
+  if (nframes < 1 || nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "nframes exceeds max_frames");
+  if (channels != 1 && channels != 3) return evh_fail(c, EVH_ERR_INVALID, "channels must be 1 or 3");
+  if (row_stride < (int64_t)sw * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
+  if (sw < 1 || sh < 1) return evh_fail(c, EVH_ERR_INVALID, "empty source frame");
+  if (nframes > 65535 || h > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "too many frames / rows for one launch");
+  int rc = configure(c, w, h, nfeatures);
+  if (rc) return rc;
+  EvhProfScope ps(c, EVH_ST_GRAY);
+  if (sw == w && sh == h) return evh_launch_gray_level0(c, d_frames, nframes, channels, row_stride, frame_stride);
+  return evh_launch_ingest_level0(c, d_frames, nframes, sw, sh, channels, row_stride, frame_stride, w, h);
+}
+
+// ORB K2..K6 on the frames whose level 0 is resident
+int orb_stages(evh_ctx* c, int nframes, int share_group) {
+  int rc;
+  { EvhProfScope ps(c, EVH_ST_PYRAMID); rc = evh_launch_pyramid(c, nframes); }
+  if (rc) return rc;
+  { EvhProfScope ps(c, EVH_ST_FAST); rc = evh_launch_fast(c, nframes, share_group); }
+  if (rc) return rc;
+  { EvhProfScope ps(c, EVH_ST_SELECT); rc = evh_launch_select(c, nframes); }
+  if (rc) return rc;
+  { EvhProfScope ps(c, EVH_ST_DESCRIBE); rc = evh_launch_describe(c, nframes); }
+  if (rc) return rc;
+  c->nframes_resident = nframes;
+  return EVH_SUCCESS;
+}
+
+int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int sh, int w, int h, int channels,
+                        int64_t row_stride, int64_t frame_stride, int nfeatures) {
+  if (!c) return EVH_ERR_INVALID;
+  const int share_group = c->fast_share ? c->fast_share_group : 0;   // set by the pair / stream entries for THIS call only
+  c->fast_share_group = 0;
+  int rc = ingest_level0(c, "evh_orb_detect_batch", d_frames, nframes, sw, sh, w, h, channels, row_stride, frame_stride, nfeatures);
+  if (rc) return rc;
+  return orb_stages(c, nframes, share_group);
+}
+
+
+// ---- multi-type pairs (frame_processing.py:91-104) ---------------------------------------------------------------------------
+int ensure_multitype(evh_ctx* c) {
+  if (c->mt.cap) return EVH_SUCCESS;
+  if (!c->sift_cap) return evh_fail(c, EVH_ERR_INVALID, "feature types beyond ORB need evh_sift_enable first");
+  const int each = std::max(c->kcap, c->sift_cap), cap = c->kcap + c->sift_cap;
+  if ((size_t)each * 5 * sizeof(int) > 150 * 1024)
+    return evh_fail(c, EVH_ERR_CAPACITY, "multi-type pairs: at most 7680 key points per frame and type in the matching filter");
+  const size_t P = (size_t)c->max_frames, K = (size_t)cap;
+  int rc;
+#define M_(call) if ((rc = (call)) != EVH_SUCCESS) return rc
+  M_(dalloc(c, &c->mt.knn_idx, P * K * 2));
+  M_(dalloc(c, &c->mt.knn_d2, P * K * 2));
+  M_(dalloc(c, &c->mt.pts, P * K * 4));
+  M_(dalloc(c, &c->mt.pts2, P * K * 4));
+  M_(dalloc(c, &c->mt.crow, P * K * 4));
+  M_(dalloc(c, &c->mt.npts, P));
+  M_(dalloc(c, &c->mt.npts2, P));
+  M_(dalloc(c, &c->mt.pstatus, P));
+  M_(dalloc(c, &c->mt.H1, P * 9));
+  M_(dalloc(c, &c->mt.mask, P * K));
+  M_(dalloc(c, &c->mt.lm, P * K * 4));
+  M_(dalloc(c, &c->mt.info, P * 8));
+  M_(dalloc(c, &c->d_acc, P * K * 4));
+  M_(dalloc(c, &c->d_nacc, P));
+  M_(dalloc(c, &c->d_accstatus, P));
+#undef M_
+  c->mt.cap = cap;
+  return EVH_SUCCESS;
+}
+
+EvhRansacArgs mt_ransac_args(evh_ctx* c, double thr, int max_iters, double conf, int force_max) {
+  EvhRansacArgs R{};
+  if (force_max && ensure_lane_scratch(c) == EVH_SUCCESS) R.lane_v = c->d_lane_v;
+  const EvhPairBufs& B = c->mt;
+  R.pts = B.pts; R.pts2 = B.pts2; R.row_stride = B.cap; R.npts = B.npts; R.npts2 = B.npts2;
+  R.status = B.pstatus; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = force_max;
+  R.mask = B.mask; R.crow = B.crow; R.lm = B.lm; R.H1 = B.H1; R.info = B.info;
+  return R;
+}
+
+// K7 + glue of ONE feature type into the multi-type pair buffers
+int match_pairs_type(evh_ctx* c, int type, int npairs, int q0, int qstep, int t0, int tstep) {
+  const EvhPairBufs& B = c->mt;
+  const bool sift = type == EVH_FEATURE_SIFT;
+  EvhKnnArgs K{};
+  K.q = sift ? c->d_sift_desc : c->d_desc; K.t = K.q;
+  K.slot_bytes = sift ? (int64_t)c->sift_cap * 128 : (int64_t)c->kcap * 32;
+  K.desc_bytes = sift ? 128 : 32;
+  const int* counts = sift ? c->d_sift_count : c->d_kp_count;
+  K.nq_arr = counts; K.nt_arr = counts;
+  K.q_slot0 = q0; K.q_slot_step = qstep; K.t_slot0 = t0; K.t_slot_step = tstep;
+  K.idx = B.knn_idx; K.d2 = B.knn_d2; K.out_stride = B.cap; K.hamming = 0;
+  int rc;
+  { EvhProfScope ps(c, EVH_ST_KNN); rc = evh_launch_knn2(c, K, npairs); }
+  if (rc) return rc;
+  EvhFilterArgs F{};
+  F.idx = B.knn_idx; F.d2 = B.knn_d2; F.knn_stride = B.cap;
+  F.xy_q = sift ? c->d_sift_xy : c->d_kp_xy; F.xy_t = F.xy_q;
+  F.xy_slot_floats = sift ? (int64_t)c->sift_cap * 2 : (int64_t)c->kcap * 2;
+  F.nq_arr = counts; F.nt_arr = counts; F.flags_arr = sift ? c->d_sift_flags : c->d_frame_flags;
+  F.q_slot0 = q0; F.q_slot_step = qstep; F.t_slot0 = t0; F.t_slot_step = tstep;
+  F.ratio = 0.5; F.min_matches = 4;
+  F.pts = B.pts; F.pts_stride = B.cap; F.npts = B.npts; F.status = B.pstatus; F.kcap = std::max(c->kcap, c->sift_cap);
+  EvhProfScope ps(c, EVH_ST_FILTER);
+  return evh_launch_filter(c, F, npairs);
+}
+
+// frames -> H with a LIST of feature types, in list order (the reference's default list is SURF, SIFT, ORB):
+// per type detect, match, RANSAC #1, static filter; concatenate; remove_double_matching; compute_homography
+int pairs_types(evh_ctx* c, const char* who, const uint8_t* d_frames, int nframes, int npairs, int stream_mode, int sw, int sh,
+                int w, int h, int channels, int64_t row_stride, int64_t frame_stride, int nfeatures, const int* types,
+                int ntypes, double thr, int max_iters, double conf, int force_max, const double* d_state_in, double* d_state_out,
+                double* d_H, int32_t* d_status) {
+  if (!types || ntypes < 1 || ntypes > 8) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": bad feature type list");
+  bool want_orb = false, want_sift = false;
+  for (int i = 0; i < ntypes; i++) {
+    if (types[i] == EVH_FEATURE_ORB) want_orb = true;
+    else if (types[i] == EVH_FEATURE_SIFT) want_sift = true;
+    else if (types[i] == EVH_FEATURE_SURF) return evh_fail(c, EVH_ERR_UNSUPPORTED, "SURF is not built (SURVEY 8f N4, second half)");
+    else return evh_fail(c, EVH_ERR_INVALID, "unknown feature type");
+  }
+  int rc = ensure_multitype(c);
+  if (rc) return rc;
+  if ((rc = join_solve(c))) return rc;
+  const int share_group = c->fast_share ? (stream_mode ? nframes : 2) : 0;
+  c->fast_share_group = 0;
+  if ((rc = ingest_level0(c, who, d_frames, nframes, sw, sh, w, h, channels, row_stride, frame_stride, nfeatures))) return rc;
+  if (want_sift && (rc = evh_launch_sift(c, nframes, w, h))) return rc;       // reads level 0 before ORB's kernels run on it
+  if (want_orb && (rc = orb_stages(c, nframes, share_group))) return rc;
+  const int q0 = 1, qstep = stream_mode ? 1 : 2, t0 = 0, tstep = stream_mode ? 1 : 2;
+  EvhRansacArgs R = mt_ransac_args(c, thr, max_iters, conf, force_max);
+  for (int i = 0; i < ntypes; i++) {
+    if ((rc = match_pairs_type(c, types[i], npairs, q0, qstep, t0, tstep))) return rc;
+    { EvhProfScope ps(c, EVH_ST_RANSAC_STATIC); rc = evh_launch_ransac_static(c, R, npairs); }
+    if (rc) return rc;
+    EvhAccArgs A{};
+    A.rows = c->mt.pts2; A.nrows = c->mt.npts2; A.status = c->mt.pstatus; A.row_stride = c->mt.cap;
+    A.acc = c->d_acc; A.nacc = c->d_nacc; A.accstatus = c->d_accstatus; A.acc_stride = c->mt.cap; A.first = i == 0;
+    if ((rc = evh_launch_accumulate(c, A, npairs))) return rc;
+  }
+  EvhMergeArgs M{};
+  M.acc = c->d_acc; M.nacc = c->d_nacc; M.accstatus = c->d_accstatus; M.acc_stride = c->mt.cap;
+  M.out = c->mt.pts2; M.nout = c->mt.npts2; M.status = c->mt.pstatus; M.out_stride = c->mt.cap;
+  if ((rc = evh_launch_merge(c, M, npairs))) return rc;
+  R.H = d_H; R.out_status = d_status;
+  if (d_state_in) { R.Hsup0 = d_state_in; R.Hprev0 = d_state_in + 9; }
+  R.state_out = d_state_out;
+  EvhProfScope ps(c, EVH_ST_RANSAC_FINAL);
+  return evh_launch_ransac_final(c, R, npairs, stream_mode ? 1 : 0, npairs);
+}
+
 }  // namespace
 
 extern "C" {
@@ -319,6 +474,12 @@ void evh_destroy(evh_ctx* c) {
                   c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  evh_sift_free(c);
+  {
+    void* mp[] = {c->mt.knn_idx, c->mt.knn_d2, c->mt.pts, c->mt.pts2, c->mt.crow, c->mt.npts, c->mt.npts2, c->mt.pstatus, c->mt.H1,
+                  c->mt.mask, c->mt.lm, c->mt.info, c->d_acc, c->d_nacc, c->d_accstatus};
+    for (void* p : mp) if (p) (void)hipFree(p);
+  }
   for (auto& s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : c->prof_pool) (void)hipEventDestroy(e);
   if (c->solve_stream) { (void)hipStreamSynchronize(c->solve_stream); (void)hipStreamDestroy(c->solve_stream); }
@@ -479,9 +640,6 @@ int evh_transform_points(evh_ctx* c, const double* h_M, int nmat, const int32_t*
   return rc;
 }
 
-static int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int sh, int w, int h, int channels,
-                        int64_t row_stride, int64_t frame_stride, int nfeatures);
-
 int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w, int h, int channels,
                          int64_t row_stride, int64_t frame_stride, int nfeatures) {
   return detect_batch(c, d_frames, nframes, w, h, w, h, channels, row_stride, frame_stride, nfeatures);
@@ -490,37 +648,6 @@ int evh_orb_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int w
 int evh_orb_detect_batch_resized(evh_ctx* c, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
                                  int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures) {
   return detect_batch(c, d_frames, nframes, src_w, src_h, w, h, channels, row_stride, frame_stride, nfeatures);
-}
-
-// (sw, sh): size of the frames handed over; (w, h): size ORB works on.  Different sizes = fused ingest (N2).
-static int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int sh, int w, int h, int channels,
-                        int64_t row_stride, int64_t frame_stride, int nfeatures) {
-  if (!c || !d_frames) return evh_fail(c, EVH_ERR_INVALID, "evh_orb_detect_batch: NULL argument");
-  const int share_group = c->fast_share ? c->fast_share_group : 0;   // set by the pair / stream entries for THIS call only
-  c->fast_share_group = 0;
-  if (nframes < 1 || nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "nframes exceeds max_frames");
-  if (channels != 1 && channels != 3) return evh_fail(c, EVH_ERR_INVALID, "channels must be 1 or 3");
-  if (row_stride < (int64_t)sw * channels) return evh_fail(c, EVH_ERR_INVALID, "row_stride smaller than a row");
-  if (sw < 1 || sh < 1) return evh_fail(c, EVH_ERR_INVALID, "empty source frame");
-  if (nframes > 65535 || h > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "too many frames / rows for one launch");
-  int rc = configure(c, w, h, nfeatures);
-  if (rc) return rc;
-  {
-    EvhProfScope ps(c, EVH_ST_GRAY);
-    if (sw == w && sh == h) rc = evh_launch_gray_level0(c, d_frames, nframes, channels, row_stride, frame_stride);
-    else rc = evh_launch_ingest_level0(c, d_frames, nframes, sw, sh, channels, row_stride, frame_stride, w, h);
-  }
-  if (rc) return rc;
-  { EvhProfScope ps(c, EVH_ST_PYRAMID); rc = evh_launch_pyramid(c, nframes); }
-  if (rc) return rc;
-  { EvhProfScope ps(c, EVH_ST_FAST); rc = evh_launch_fast(c, nframes, share_group); }
-  if (rc) return rc;
-  { EvhProfScope ps(c, EVH_ST_SELECT); rc = evh_launch_select(c, nframes); }
-  if (rc) return rc;
-  { EvhProfScope ps(c, EVH_ST_DESCRIBE); rc = evh_launch_describe(c, nframes); }
-  if (rc) return rc;
-  c->nframes_resident = nframes;
-  return EVH_SUCCESS;
 }
 
 int evh_orb_capacity(const evh_ctx* c) { return c ? c->kcap : EVH_ERR_INVALID; }
@@ -870,6 +997,139 @@ int evh_pair_from_slots(evh_ctx* c, int cur_slot, int prev_slot, const double* h
   EVH_HIP(c, hipMemcpy(h_H, c->d_small, 9 * sizeof(double), hipMemcpyDeviceToHost));
   EVH_HIP(c, hipMemcpy(h_status, c->d_small + 32, sizeof(int), hipMemcpyDeviceToHost));
   return EVH_SUCCESS;
+}
+
+
+// ---- N4: SIFT ------------------------------------------------------------------------------------------------------------------
+int evh_sift_enable(evh_ctx* c, int max_sift_features) {
+  if (!c) return EVH_ERR_INVALID;
+  return evh_sift_allocate(c, max_sift_features);
+}
+
+int evh_sift_capacity(const evh_ctx* c) { return c ? c->sift_cap : EVH_ERR_INVALID; }
+
+int evh_sift_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                          int64_t row_stride, int64_t frame_stride, int w, int h) {
+  if (!c) return EVH_ERR_INVALID;
+  if (!c->sift_cap) return evh_fail(c, EVH_ERR_INVALID, "evh_sift_detect_batch: call evh_sift_enable first");
+  int rc = join_solve(c);
+  if (rc) return rc;
+  const int nf = c->geom_valid ? c->g.nfeatures : std::min(500, c->max_features);
+  if ((rc = ingest_level0(c, "evh_sift_detect_batch", d_frames, nframes, src_w, src_h, w, h, channels, row_stride, frame_stride, nf)))
+    return rc;
+  c->nframes_resident = 0;            // level 0 was rewritten: the ORB results of an earlier call no longer match it
+  return evh_launch_sift(c, nframes, w, h);
+}
+
+int evh_sift_count(evh_ctx* c, int frame) {
+  if (!c || frame < 0 || frame >= c->sift_frames_resident) return evh_fail(c, EVH_ERR_INVALID, "bad SIFT frame slot");
+  int n = 0, fl = 0;
+  EVH_HIP(c, hipMemcpyAsync(&n, c->d_sift_count + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(&fl, c->d_sift_flags + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  if (fl) return evh_fail(c, EVH_ERR_CAPACITY, "more SIFT key points (or scale-space extrema) than evh_sift_enable reserved for a frame");
+  return n;
+}
+
+int evh_sift_download(evh_ctx* c, int frame, float* h_xy, float* h_desc, int32_t* h_octave, float* h_size, float* h_angle,
+                      float* h_response) {
+  const int n = evh_sift_count(c, frame);
+  if (n <= 0) return n;
+  const size_t o = (size_t)frame * c->sift_cap;
+  std::vector<float> rec((size_t)n * 8);
+  std::vector<uint8_t> d8;
+  EVH_HIP(c, hipMemcpyAsync(rec.data(), c->d_sift_kp + o * 8, sizeof(float) * 8 * n, hipMemcpyDeviceToHost, c->stream));
+  if (h_desc) {
+    d8.resize((size_t)n * 128);
+    EVH_HIP(c, hipMemcpyAsync(d8.data(), c->d_sift_desc + o * 128, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
+  }
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    const float* r = &rec[(size_t)i * 8];
+    if (h_xy) { h_xy[2 * i] = r[0]; h_xy[2 * i + 1] = r[1]; }
+    if (h_size) h_size[i] = r[2];
+    if (h_angle) h_angle[i] = r[3];
+    if (h_response) h_response[i] = r[4];
+    if (h_octave) memcpy(&h_octave[i], &r[5], 4);
+  }
+  if (h_desc) for (size_t i = 0; i < (size_t)n * 128; i++) h_desc[i] = (float)d8[i];
+  return n;
+}
+
+int evh_sift_octave_info(const evh_ctx* c, int octave, int* w, int* h) {
+  if (!c || !c->sift_geom_valid || octave < 0) return EVH_ERR_INVALID;
+  if (octave >= c->sg.noct) return 1;
+  if (w) *w = c->sg.ow[octave]; if (h) *h = c->sg.oh[octave];
+  return EVH_SUCCESS;
+}
+
+int evh_sift_download_gauss(evh_ctx* c, int frame, int octave, int layer, float* h_pixels) {
+  if (!c || !c->sift_geom_valid || !h_pixels || octave < 0 || octave >= c->sg.noct || layer < 0 || layer > 5 || frame < 0)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_sift_download_gauss: bad argument");
+  // only the LAST group's scale space is resident
+  const int g0 = ((c->sift_frames_resident - 1) / c->sift_group) * c->sift_group;
+  if (frame < g0 || frame >= c->sift_frames_resident) return evh_fail(c, EVH_ERR_INVALID, "evh_sift_download_gauss: that frame's scale space is no longer resident");
+  const EvhSiftGeom& g = c->sg;
+  const float* src = c->d_sift_pyr + (int64_t)(frame - g0) * c->sift_pyr_frame_floats + g.ooff[octave] + (int64_t)layer * g.os[octave] * g.oh[octave];
+  EVH_HIP(c, hipMemcpy2DAsync(h_pixels, sizeof(float) * g.ow[octave], src, sizeof(float) * g.os[octave], sizeof(float) * g.ow[octave],
+                              g.oh[octave], hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  return EVH_SUCCESS;
+}
+
+int evh_match_knn2_l2f32(evh_ctx* c, const float* d_q, int nq, const float* d_t, int nt, int dim, int32_t* d_idx, float* d_dist) {
+  if (!c || !d_idx || !d_dist || nq < 0 || nt < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_match_knn2_l2f32: bad argument");
+  if (nq == 0) return EVH_SUCCESS;
+  if (((uintptr_t)d_q | (uintptr_t)d_t) & 15) return evh_fail(c, EVH_ERR_INVALID, "descriptor buffers must be 16-byte aligned");
+  EvhKnnF32Args A{d_q, d_t, nq, nt, dim, d_idx, d_dist};
+  return evh_launch_knn2_f32(c, A);
+}
+
+int evh_ratio_unique_filter_f32(evh_ctx* c, const int32_t* d_idx, const float* d_dist, int nq, int nt, const float* d_xy_q,
+                                const float* d_xy_t, double ratio, int min_matches, float* d_pts, int* h_count, int* h_status) {
+  if (!c || !d_idx || !d_dist || !d_xy_q || !d_xy_t || !d_pts || !h_count || !h_status || nq < 0 || nt < 0)
+    return evh_fail(c, EVH_ERR_INVALID, "evh_ratio_unique_filter_f32: bad argument");
+  const int kc = std::max(std::max(nq, nt), 1);
+  if ((size_t)kc * 5 * sizeof(int) > 150 * 1024) return evh_fail(c, EVH_ERR_CAPACITY, "evh_ratio_unique_filter_f32: too many rows");
+  if (((uintptr_t)d_pts) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_pts must be 16-byte aligned");
+  int* d_cnt = reinterpret_cast<int*>(c->d_small);
+  EvhFilterArgs F{};
+  F.idx = d_idx; F.d2 = reinterpret_cast<const uint32_t*>(d_dist); F.d2_is_dist = 1; F.knn_stride = nq;
+  F.xy_q = d_xy_q; F.xy_t = d_xy_t; F.xy_slot_floats = 0;
+  F.nq_fixed = nq; F.nt_fixed = nt; F.ratio = ratio; F.min_matches = min_matches;
+  F.pts = d_pts; F.pts_stride = nq; F.npts = d_cnt; F.status = d_cnt + 1; F.kcap = kc;
+  int rc = evh_launch_filter(c, F, 1);
+  if (rc) return rc;
+  int host[2];
+  EVH_HIP(c, hipMemcpyAsync(host, d_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  *h_count = host[0]; *h_status = host[1];
+  return EVH_SUCCESS;
+}
+
+int evh_pair_homography_batch_types(evh_ctx* c, const uint8_t* d_frames, int npairs, int mode, int src_w, int src_h,
+                                    int channels, int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures,
+                                    const int32_t* h_types, int ntypes, double ransac_thr, int ransac_max_iters,
+                                    double ransac_conf, int force_max_iters, double* d_H, int32_t* d_status) {
+  if (!c || !d_frames || !d_H || !d_status || npairs < 1) return evh_fail(c, EVH_ERR_INVALID, "evh_pair_homography_batch_types: bad argument");
+  if (mode != EVH_MODE_INDEPENDENT_PAIRS && mode != EVH_MODE_STREAM) return evh_fail(c, EVH_ERR_INVALID, "unknown mode");
+  const int nframes = mode == EVH_MODE_INDEPENDENT_PAIRS ? 2 * npairs : npairs + 1;
+  if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "batch needs more frame slots than max_frames");
+  return pairs_types(c, "evh_pair_homography_batch_types", d_frames, nframes, npairs, mode == EVH_MODE_STREAM, src_w, src_h, w, h,
+                     channels, row_stride, frame_stride, nfeatures, h_types, ntypes, ransac_thr, ransac_max_iters, ransac_conf,
+                     force_max_iters, nullptr, nullptr, d_H, d_status);
+}
+
+int evh_stream_homography_batch_types(evh_ctx* c, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                                      int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures,
+                                      const int32_t* h_types, int ntypes, double ransac_thr, int ransac_max_iters,
+                                      double ransac_conf, int force_max_iters, const double* d_state_in, double* d_state_out,
+                                      double* d_H, int32_t* d_status) {
+  if (!c || !d_frames || !d_H || !d_status || nframes < 2) return evh_fail(c, EVH_ERR_INVALID, "evh_stream_homography_batch_types: bad argument");
+  if (nframes > c->max_frames) return evh_fail(c, EVH_ERR_CAPACITY, "chunk needs more frame slots than max_frames");
+  return pairs_types(c, "evh_stream_homography_batch_types", d_frames, nframes, nframes - 1, 1, src_w, src_h, w, h, channels,
+                     row_stride, frame_stride, nfeatures, h_types, ntypes, ransac_thr, ransac_max_iters, ransac_conf,
+                     force_max_iters, d_state_in, d_state_out, d_H, d_status);
 }
 
 }  // extern "C"

@@ -36,6 +36,24 @@ struct EvhGeom {
   int total_tiles;
 };
 
+// N4: SIFT scale-space geometry of one frame size (octave 0 = the frame doubled, 6 Gaussian layers per octave)
+#define EVH_SIFT_MAXOCT 13
+struct EvhSiftGeom {
+  int w, h, noct;
+  int ow[EVH_SIFT_MAXOCT], oh[EVH_SIFT_MAXOCT], os[EVH_SIFT_MAXOCT];   // octave width / height / row stride (floats)
+  int64_t ooff[EVH_SIFT_MAXOCT];                                       // float offset of an octave's layer 0 inside a frame
+  int64_t frame_floats, tmp_floats;
+};
+
+// per-pair working buffers of the matching / RANSAC stages (row stride `cap` rows per pair)
+struct EvhPairBufs {
+  int cap = 0;
+  int32_t* knn_idx = nullptr; uint32_t* knn_d2 = nullptr;
+  float* pts = nullptr; float* pts2 = nullptr; float* crow = nullptr;
+  int* npts = nullptr; int* npts2 = nullptr; int* pstatus = nullptr;
+  double* H1 = nullptr; uint8_t* mask = nullptr; double* lm = nullptr; int* info = nullptr;
+};
+
 struct evh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -96,6 +114,22 @@ struct evh_ctx {
   double* d_small = nullptr;      // small staging area for single-problem entries (H, counts)
   char* d_scratch = nullptr;      // growable scratch of the host-pointer entries (N1 / N3): no hipMalloc per call
   size_t scratch_bytes = 0;
+  // ---- N4: SIFT (allocated by evh_sift_enable) ----
+  int sift_cap = 0, sift_cand_cap = 0, sift_group = 0, sift_frames_resident = 0;
+  EvhSiftGeom sg{}; bool sift_geom_valid = false;
+  int64_t sift_pyr_frame_floats = 0, sift_tmp_frame_floats = 0;
+  float* d_sift_pyr = nullptr;    // [group][frame_floats] Gaussian scale space
+  float* d_sift_tmp = nullptr;    // [group][octave-0 layer] row-pass temporary
+  uint32_t* d_sift_cand = nullptr; int* d_sift_ncand = nullptr;   // extrema: octave<<28 | layer<<26 | r<<13 | c
+  float* d_sift_raw = nullptr; int* d_sift_nraw = nullptr;        // [F][cap][8] key points before the sort
+  float* d_sift_srt = nullptr;    // [F][cap][8] sorted
+  float* d_sift_kp = nullptr;     // [F][cap][8] final records: x, y, size, angle, response, octave bits
+  float* d_sift_xy = nullptr;     // [F][cap][2]
+  uint8_t* d_sift_desc = nullptr; // [F][cap][128] descriptor VALUES (0..255; the operator returns them as float32)
+  int* d_sift_count = nullptr; int* d_sift_flags = nullptr;
+  // multi-type pairs (frame_processing.py:91-104): per-type match / static rows, their concatenation, the merged rows
+  EvhPairBufs mt;                 // stride mt.cap = kcap + sift_cap
+  float* d_acc = nullptr; int* d_nacc = nullptr; int* d_accstatus = nullptr;
   size_t bytes_allocated = 0;
   std::string err;
   // per-stage timing (evh_profile_*)
@@ -135,6 +169,10 @@ int evh_launch_superposition_scan(evh_ctx* c, const double* d_H, int n, double* 
 int evh_launch_transform_points(evh_ctx* c, const double* d_M, const int* d_idx, const double* d_pts, int n, double kx,
                                 double ky, int decimals, double* d_out);
 int evh_launch_fixed_plane(evh_ctx* c, const double* d_H, int n, int w, int h, double* d_field, unsigned long long* d_max);
+// N4: SIFT (evh_sift.hip)
+int evh_sift_allocate(evh_ctx* c, int max_sift_features);
+void evh_sift_free(evh_ctx* c);
+int evh_launch_sift(evh_ctx* c, int nframes, int w, int h);
 int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
                            int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
                            int64_t dst_img_stride);

@@ -13,6 +13,7 @@ struct EvhKnnArgs {
   int32_t* idx; uint32_t* d2;
   int64_t out_stride;             // rows per pair in idx / d2
   int hamming;
+  int desc_bytes;                 // 32 (ORB) or 128 (SIFT descriptor values as bytes); 0 = 32
 };
 
 struct EvhFilterArgs {
@@ -27,8 +28,26 @@ struct EvhFilterArgs {
   float* pts; int64_t pts_stride; // rows per pair
   int* npts; int* status;
   int kcap;                       // LDS sizing: >= max(nq, nt)
+  int d2_is_dist;                 // d2 holds the float32 bits of the (square-rooted) distance: float descriptors
+};
+
+// BruteForce 2-NN on float32 descriptors (SIFT / SURF rows of `dim` floats, dim = 64 or 128)
+struct EvhKnnF32Args { const float* q; const float* t; int nq, nt, dim; int32_t* idx; float* dist; };
+
+// multi-type pairs (frame_processing.py:91-104): append one feature type's static rows, then remove_double_matching
+struct EvhAccArgs {
+  const float* rows; const int* nrows; const int* status; int64_t row_stride;   // per-type static rows [pair][row_stride][4]
+  float* acc; int* nacc; int* accstatus; int64_t acc_stride;                    // concatenation [pair][acc_stride][4]
+  int first;                                                                    // first type of the list: resets the concatenation
+};
+struct EvhMergeArgs {
+  const float* acc; const int* nacc; const int* accstatus; int64_t acc_stride;
+  float* out; int* nout; int* status; int64_t out_stride;
 };
 
 struct evh_ctx;
+int evh_launch_knn2_f32(evh_ctx* c, const EvhKnnF32Args& A);
+int evh_launch_accumulate(evh_ctx* c, const EvhAccArgs& A, int npairs);
+int evh_launch_merge(evh_ctx* c, const EvhMergeArgs& A, int npairs);
 int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs);
 int evh_launch_filter(evh_ctx* c, const EvhFilterArgs& A, int npairs);

@@ -4,25 +4,35 @@
 // Distances are exact integers: D = |q|^2 + |t|^2 - 2 q.t with v_dot4_u32_u8 on LDS-staged train tiles.
 #include "evh_internal.h"
 #include "evh_match.h"
+#include <cfloat>
 
 namespace {
 
 #define MT_TILE 512  // train descriptors per LDS tile (16 KB)
 
-__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t acc) {
-#if __has_builtin(__builtin_amdgcn_udot4)
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t acc) {   // v_dot4_u32_u8
   return __builtin_amdgcn_udot4(a, b, acc, false);
-#else
-  return acc + (a & 0xFF) * (b & 0xFF) + ((a >> 8) & 0xFF) * ((b >> 8) & 0xFF) + ((a >> 16) & 0xFF) * ((b >> 16) & 0xFF) +
-         (a >> 24) * (b >> 24);
-#endif
+}
+
+// a < b as the operator sees it: distances are compared after sqrt in float32 (batchDistance: dist = sqrt(D), insertion
+// on strictly smaller dist).  sqrtf is strictly monotone on integers below 2^22 (spacing of sqrt >= 2^-12 > half an ulp
+// there); above, two different D can round to the same float, and then they tie.  32-byte descriptors never get there
+// (D <= 2 080 800); 128-byte ones can (D <= 8 323 200).
+__device__ __forceinline__ bool dist_lt(uint32_t a, uint32_t b) {
+  if (a >= b) return false;
+  if (a < (1u << 22) || b == 0xFFFFFFFFu) return true;
+  return sqrtf((float)a) < sqrtf((float)b);
 }
 
 // one workgroup (256 threads) per (pair, chunk of 256 queries): blockIdx.y = chunk, so that a few pairs with many
-// descriptors (4K frames, N = 4000) still fill the chip; the train set is streamed through LDS by every chunk
+// descriptors (4K frames, N = 4000) still fill the chip; the train set is streamed through LDS by every chunk.
+// NV = uint4 per descriptor: 2 (32 bytes, ORB) or 8 (128 bytes: SIFT's descriptor values, 0..255 each -- the operator
+// holds them as float32 and its float accumulation of the squared differences is exact, every partial sum being an
+// integer below 2^24).
+template <int NV, int TILE>
 __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
-  __shared__ uint4 tdesc[MT_TILE * 2];
-  __shared__ uint32_t tnorm[MT_TILE];
+  __shared__ uint4 tdesc[TILE * NV];
+  __shared__ uint32_t tnorm[TILE];
   const int p = blockIdx.x, tid = threadIdx.x;
   const int qs = A.q_slot0 + p * A.q_slot_step, ts = A.t_slot0 + p * A.t_slot_step;
   const int nq = A.nq_arr ? A.nq_arr[qs] : A.nq_fixed;
@@ -34,45 +44,61 @@ __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
   for (int q0 = blockIdx.y * 256; q0 < nq; q0 += 256 * gridDim.y) {   // workgroup-uniform bounds
     const int qi = q0 + tid;
     const bool act = qi < nq;
-    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-    if (act) { qa = Q[2 * qi]; qb = Q[2 * qi + 1]; }
+    uint4 qv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) qv[v] = act ? Q[NV * qi + v] : make_uint4(0, 0, 0, 0);
     uint32_t qn = 0;
     if (!A.hamming) {
-      qn = dot4(qa.x, qa.x, qn); qn = dot4(qa.y, qa.y, qn); qn = dot4(qa.z, qa.z, qn); qn = dot4(qa.w, qa.w, qn);
-      qn = dot4(qb.x, qb.x, qn); qn = dot4(qb.y, qb.y, qn); qn = dot4(qb.z, qb.z, qn); qn = dot4(qb.w, qb.w, qn);
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        qn = dot4(qv[v].x, qv[v].x, qn); qn = dot4(qv[v].y, qv[v].y, qn); qn = dot4(qv[v].z, qv[v].z, qn); qn = dot4(qv[v].w, qv[v].w, qn);
+      }
     }
     uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
     int i0 = -1, i1 = -1;
-    for (int t0 = 0; t0 < nt; t0 += MT_TILE) {
-      const int tn = min(MT_TILE, nt - t0);
+    for (int t0 = 0; t0 < nt; t0 += TILE) {
+      const int tn = min(TILE, nt - t0);
       __syncthreads();
-      for (int i = tid; i < tn * 2; i += 256) tdesc[i] = T[2 * t0 + i];
+      for (int i = tid; i < tn * NV; i += 256) tdesc[i] = T[NV * t0 + i];
       __syncthreads();
       if (!A.hamming)
         for (int i = tid; i < tn; i += 256) {
-          uint4 a = tdesc[2 * i], b = tdesc[2 * i + 1];
           uint32_t n = 0;
-          n = dot4(a.x, a.x, n); n = dot4(a.y, a.y, n); n = dot4(a.z, a.z, n); n = dot4(a.w, a.w, n);
-          n = dot4(b.x, b.x, n); n = dot4(b.y, b.y, n); n = dot4(b.z, b.z, n); n = dot4(b.w, b.w, n);
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            const uint4 a = tdesc[NV * i + v];
+            n = dot4(a.x, a.x, n); n = dot4(a.y, a.y, n); n = dot4(a.z, a.z, n); n = dot4(a.w, a.w, n);
+          }
           tnorm[i] = n;
         }
       __syncthreads();
       if (act) {
         for (int j = 0; j < tn; j++) {
-          const uint4 ta = tdesc[2 * j], tb = tdesc[2 * j + 1];
           uint32_t d;
           if (A.hamming) {
-            d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-                __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+            d = 0;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              const uint4 ta = tdesc[NV * j + v];
+              d += __popc(qv[v].x ^ ta.x) + __popc(qv[v].y ^ ta.y) + __popc(qv[v].z ^ ta.z) + __popc(qv[v].w ^ ta.w);
+            }
           } else {
             uint32_t s = 0;
-            s = dot4(qa.x, ta.x, s); s = dot4(qa.y, ta.y, s); s = dot4(qa.z, ta.z, s); s = dot4(qa.w, ta.w, s);
-            s = dot4(qb.x, tb.x, s); s = dot4(qb.y, tb.y, s); s = dot4(qb.z, tb.z, s); s = dot4(qb.w, tb.w, s);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              const uint4 ta = tdesc[NV * j + v];
+              s = dot4(qv[v].x, ta.x, s); s = dot4(qv[v].y, ta.y, s); s = dot4(qv[v].z, ta.z, s); s = dot4(qv[v].w, ta.w, s);
+            }
             d = qn + tnorm[j] - 2u * s;
           }
           // ascending train order, strict '<': ties keep the lowest train index
-          if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = t0 + j; }
-          else if (d < b1) { b1 = d; i1 = t0 + j; }
+          if (NV == 2) {
+            if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = t0 + j; }
+            else if (d < b1) { b1 = d; i1 = t0 + j; }
+          } else {
+            if (dist_lt(d, b0)) { b1 = b0; i1 = i0; b0 = d; i0 = t0 + j; }
+            else if (dist_lt(d, b1)) { b1 = d; i1 = t0 + j; }
+          }
         }
       }
     }
@@ -80,6 +106,44 @@ __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
       oidx[2 * qi] = i0; oidx[2 * qi + 1] = i1;
       od2[2 * qi] = b0; od2[2 * qi + 1] = b1;
     }
+  }
+}
+
+// BruteForce knnMatch(q, t, 2) on float32 descriptors (matching.py:102-108 with SIFT / SURF rows): hal::normL2Sqr_ --
+// two 4-lane partial sums over steps of 8 elements, (d0 + d1) then its four lanes added left to right -- dist = sqrt,
+// insertion on strictly smaller dist.  One thread per query (its row in registers); the train rows are wave-uniform
+// and come through scalar loads.
+template <int DIM>
+__global__ __launch_bounds__(64) void k_knn2_f32(EvhKnnF32Args A) {
+  const int qi = blockIdx.x * 64 + threadIdx.x;
+  const bool act = qi < A.nq;
+  float q[DIM];
+  const float4* Q = reinterpret_cast<const float4*>(A.q + (int64_t)(act ? qi : 0) * DIM);
+#pragma unroll
+  for (int k = 0; k < DIM / 4; k++) { const float4 v = Q[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
+  float b0 = FLT_MAX, b1 = FLT_MAX;
+  int i0 = -1, i1 = -1;
+  for (int j = 0; j < A.nt; j++) {
+    const float* t = A.t + (int64_t)j * DIM;
+    float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < DIM; k += 8)
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const float t0 = q[k + l] - t[k + l], t1 = q[k + 4 + l] - t[k + 4 + l];
+        d0[l] = d0[l] + t0 * t0;
+        d1[l] = d1[l] + t1 * t1;
+      }
+    const float u0 = d0[0] + d1[0], u1 = d0[1] + d1[1], u2 = d0[2] + d1[2], u3 = d0[3] + d1[3];
+    const float ds = sqrtf(u0 + u1 + u2 + u3);
+    if (ds < b1) {
+      if (b0 > ds) { b1 = b0; i1 = i0; b0 = ds; i0 = j; }
+      else { b1 = ds; i1 = j; }
+    }
+  }
+  if (act) {
+    A.idx[2 * qi] = i0; A.idx[2 * qi + 1] = i1;
+    A.dist[2 * qi] = b0; A.dist[2 * qi + 1] = b1;
   }
 }
 
@@ -132,8 +196,8 @@ __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
   for (int i = tid; i < nq; i += 256) {
     bool pass = false;
     if (idx[2 * i] >= 0 && idx[2 * i + 1] >= 0) {
-      double dist0 = (double)sqrtf((float)d2[2 * i]);
-      double dist1 = (double)sqrtf((float)d2[2 * i + 1]);
+      double dist0 = A.d2_is_dist ? (double)__uint_as_float(d2[2 * i]) : (double)sqrtf((float)d2[2 * i]);
+      double dist1 = A.d2_is_dist ? (double)__uint_as_float(d2[2 * i + 1]) : (double)sqrtf((float)d2[2 * i + 1]);
       pass = dist0 < dist1 * A.ratio;
     }
     keep[i] = pass ? 1 : 0;
@@ -178,6 +242,64 @@ __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
   if (tid == 0) { A.npts[p] = u; A.status[p] = EVH_PAIR_OK; }
 }
 
+
+// frame_processing.py:91-98: the static rows of one feature type are appended to the pair's concatenation; a type that
+// raised (NoMatchesException) fails the pair with ITS status and nothing after it counts (the exception propagates)
+__global__ __launch_bounds__(256) void k_accumulate(EvhAccArgs A) {
+  const int p = blockIdx.x;
+  __shared__ int s_base, s_go;
+  if (threadIdx.x == 0) {
+    int st = A.first ? 0 : A.accstatus[p];
+    int base = A.first ? 0 : A.nacc[p];
+    int go = 0;
+    if (st == 0) {
+      if (A.status[p] != 0) { st = A.status[p]; base = 0; }
+      else go = 1;
+    }
+    s_base = base; s_go = go;
+    A.accstatus[p] = st;
+    A.nacc[p] = go ? base + A.nrows[p] : base;
+  }
+  __syncthreads();
+  if (!s_go) return;
+  const int n = A.nrows[p], base = s_base;
+  const float4* src = reinterpret_cast<const float4*>(A.rows + (int64_t)p * A.row_stride * 4);
+  float4* dst = reinterpret_cast<float4*>(A.acc + (int64_t)p * A.acc_stride * 4);
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (base + i < A.acc_stride) dst[base + i] = src[i];
+}
+
+// frame_processing.py:102-104: remove_double_matching over the concatenated rows of all feature types (utils.py:60-68):
+// key = exact (ax, ay), first occurrence keeps its place, the LAST occurrence gives b
+__global__ __launch_bounds__(256) void k_merge(EvhMergeArgs A) {
+  __shared__ int wave_tot[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int st = A.accstatus[p];
+  if (st != 0) {
+    if (tid == 0) { A.nout[p] = 0; A.status[p] = st; }
+    return;
+  }
+  const int m = min(A.nacc[p], (int)A.acc_stride);
+  const float4* R = reinterpret_cast<const float4*>(A.acc + (int64_t)p * A.acc_stride * 4);
+  float4* out = reinterpret_cast<float4*>(A.out + (int64_t)p * A.out_stride * 4);
+  int u = 0;
+  for (int c0 = 0; c0 < m; c0 += 256) {          // workgroup-uniform
+    const int i = c0 + tid;
+    bool first = false; int last = i;
+    if (i < m) {
+      const float ax = R[i].x, ay = R[i].y;
+      first = true;
+      for (int j = 0; j < m; j++) {
+        const float4 o = R[j];
+        if (o.x == ax && o.y == ay) { if (j < i) first = false; if (j > last) last = j; }
+      }
+    }
+    const int slot = block_ordered_slot(first, wave_tot, u);
+    if (first && slot < A.out_stride) { const float4 a = R[i], b = R[last]; out[slot] = make_float4(a.x, a.y, b.z, b.w); }
+  }
+  if (tid == 0) { A.nout[p] = u; A.status[p] = 0; }
+}
+
 }  // namespace
 
 int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs) {
@@ -185,7 +307,31 @@ int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs) {
   // chunks of 256 queries in grid.y, bounded by the largest possible query count
   const int nq_max = A.nq_arr ? A.out_stride : A.nq_fixed;
   const int chunks = std::max(1, std::min((nq_max + 255) / 256, 64));
-  hipLaunchKernelGGL(k_knn2, dim3(npairs, chunks), dim3(256), 0, c->stream, A);
+  if (A.desc_bytes == 128) hipLaunchKernelGGL((k_knn2<8, 128>), dim3(npairs, chunks), dim3(256), 0, c->stream, A);
+  else hipLaunchKernelGGL((k_knn2<2, MT_TILE>), dim3(npairs, chunks), dim3(256), 0, c->stream, A);
+  EVH_HIP(c, hipGetLastError());
+  return EVH_SUCCESS;
+}
+
+int evh_launch_knn2_f32(evh_ctx* c, const EvhKnnF32Args& A) {
+  if (A.nq <= 0) return EVH_SUCCESS;
+  if (A.dim == 128) hipLaunchKernelGGL(k_knn2_f32<128>, dim3((A.nq + 63) / 64), dim3(64), 0, c->stream, A);
+  else if (A.dim == 64) hipLaunchKernelGGL(k_knn2_f32<64>, dim3((A.nq + 63) / 64), dim3(64), 0, c->stream, A);
+  else return evh_fail(c, EVH_ERR_UNSUPPORTED, "float descriptors: 64 or 128 elements per row (SURF / SIFT)");
+  EVH_HIP(c, hipGetLastError());
+  return EVH_SUCCESS;
+}
+
+int evh_launch_accumulate(evh_ctx* c, const EvhAccArgs& A, int npairs) {
+  if (npairs <= 0) return EVH_SUCCESS;
+  hipLaunchKernelGGL(k_accumulate, dim3(npairs), dim3(256), 0, c->stream, A);
+  EVH_HIP(c, hipGetLastError());
+  return EVH_SUCCESS;
+}
+
+int evh_launch_merge(evh_ctx* c, const EvhMergeArgs& A, int npairs) {
+  if (npairs <= 0) return EVH_SUCCESS;
+  hipLaunchKernelGGL(k_merge, dim3(npairs), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }

@@ -14,6 +14,9 @@
  *   evh_transform_points          from_original_to_fix / from_fix_to_original       fixed_coordinate_system.py:19-122
  *   evh_find_homography_ransac    cv2.findHomography(a,b,cv2.RANSAC,3.0) matching.py:156-157; utils.py:356-358
  *   evh_static_filter             find_point_displacement + get_largest_group_points   utils.py:258-325
+ *   evh_sift_detect_batch         cv2.xfeatures2d.SIFT_create().detectAndCompute   frame_processing.py:62-64
+ *   evh_match_knn2_l2f32          knnMatch on float32[N,128] descriptors            matching.py:102-108
+ *   evh_*_homography_batch_types  concatenate_all_features_types over a type list   frame_processing.py:91-104
  *   evh_pair_homography_batch     the per-pair body of get_homography_dict video_processing.py:67-105
  *                                 (FrameProcessing.concatenate_all_features_types frame_processing.py:73-108
  *                                  + compute_homography utils.py:328-363 + matrix_superposition utils.py:118-145)
@@ -248,6 +251,53 @@ int evh_match_static_from_slots(evh_ctx* ctx, int cur_slot, int prev_slot, float
 /* compute_homography (utils.py:328-363) on host point rows f32[n,4] */
 int evh_compute_homography(evh_ctx* ctx, const float* h_pts, int n, const double* h_Hsup, double* h_H,
                            int* h_status);
+
+/* ---- N4: SIFT and the reference's multi-type pairs --------------------------------------------------------- */
+/* feature types of frame_processing.py:59-67; a list is processed in its own order (reference default: SURF, SIFT, ORB) */
+enum { EVH_FEATURE_ORB = 0, EVH_FEATURE_SIFT = 1, EVH_FEATURE_SURF = 2 /* not built: EVH_ERR_UNSUPPORTED */ };
+/* Reserves the SIFT buffers of a context: max_sift_features key points per frame slot (SIFT_create() keeps every key
+ * point -- 2 500 on a textured 400x224 frame), the float scale space of a group of frames.  Call once, before the entries
+ * below.  A frame that delivers more is flagged: its pairs get EVH_PAIR_CAPACITY, evh_sift_count / _download fail.    */
+int evh_sift_enable(evh_ctx* ctx, int max_sift_features);
+int evh_sift_capacity(const evh_ctx* ctx);
+/* cv2.xfeatures2d.SIFT_create().detectAndCompute(frame, None) (frame_processing.py:62-64) on a batch of frames of
+ * src_w x src_h, working size (w, h) as in evh_orb_detect_batch_resized (equal sizes = no resize).  Results stay
+ * resident (frame slots 0..nframes-1).  OpenCV 3.4.2 defaults: 3 layers per octave, contrast 0.04, edge 10, sigma 1.6. */
+int evh_sift_detect_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                          int64_t row_stride, int64_t frame_stride, int w, int h);
+int evh_sift_count(evh_ctx* ctx, int frame);
+/* one frame's key points to HOST arrays (any may be NULL), in the operator's own order (removeDuplicatedSorted: by x,
+ * then y, ...): xy f32[n,2], desc f32[n,128] (integer values 0..255 as the operator returns them), octave i32[n] (packed
+ * like KeyPoint::octave: octave & 255 | layer << 8 | ...), size, angle (degrees), response.  Returns n.             */
+int evh_sift_download(evh_ctx* ctx, int frame, float* h_xy, float* h_desc, int32_t* h_octave, float* h_size,
+                      float* h_angle, float* h_response);
+/* test / inspection hooks: octave geometry (returns 1 past the last octave) and one Gaussian layer (0..5) of the
+ * scale space of a frame of the last detect call (octave 0 = the frame doubled)                                   */
+int evh_sift_octave_info(const evh_ctx* ctx, int octave, int* w, int* h);
+int evh_sift_download_gauss(evh_ctx* ctx, int frame, int octave, int layer, float* h_pixels /* h*w tight */);
+/* DescriptorMatcher("BruteForce").knnMatch(q, t, 2) on FLOAT descriptors (matching.py:102-108 with the float32[N,128]
+ * rows of SIFT / SURF; dim = 64 or 128): d_idx i32[nq,2] (-1 = missing neighbour), d_dist f32[nq,2] (L2 distances,
+ * summed in the operator's order).  Ties -> lowest train index.                                                      */
+int evh_match_knn2_l2f32(evh_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt, int dim, int32_t* d_idx,
+                         float* d_dist);
+/* evh_ratio_unique_filter on the float distances of evh_match_knn2_l2f32                                             */
+int evh_ratio_unique_filter_f32(evh_ctx* ctx, const int32_t* d_idx, const float* d_dist, int nq, int nt,
+                                const float* d_xy_q, const float* d_xy_t, double ratio, int min_matches, float* d_pts,
+                                int* h_count, int* h_status);
+/* The fused entries with a LIST of feature types (h_types: EVH_FEATURE_*, ntypes entries, processed in list order), i.e.
+ * FrameProcessing(frame, features_type_list).concatenate_all_features_types (frame_processing.py:91-104): per type
+ * detect + match + RANSAC #1 + static filter, the static rows of all types concatenated, remove_double_matching again,
+ * then compute_homography.  A type that fails (NoMatchesException) fails the pair with its status.  (src_w, src_h) /
+ * (w, h) as in evh_stream_homography_batch_resized.  Needs evh_sift_enable when the list holds SIFT.  Do not synchronise. */
+int evh_pair_homography_batch_types(evh_ctx* ctx, const uint8_t* d_frames, int npairs, int mode, int src_w, int src_h,
+                                    int channels, int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures,
+                                    const int32_t* h_types, int ntypes, double ransac_thr, int ransac_max_iters,
+                                    double ransac_conf, int force_max_iters, double* d_H, int32_t* d_status);
+int evh_stream_homography_batch_types(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int src_w, int src_h,
+                                      int channels, int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures,
+                                      const int32_t* h_types, int ntypes, double ransac_thr, int ransac_max_iters,
+                                      double ransac_conf, int force_max_iters, const double* d_state_in,
+                                      double* d_state_out, double* d_H, int32_t* d_status);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,23 @@ int evo_orb_detect(const uint8_t* gray, int w, int h, int nfeatures, float* xy, 
 void evo_sincos(double x, double* s, double* c);
 float evo_fast_atan2(float y, float x);
 
+/* ---- N4: SIFT (frame_processing.py:62-64 cv2.xfeatures2d.SIFT_create().detectAndCompute), evz_sift.cpp ---- */
+/* RESTATED FROM RECALL, PARITY UNPINNED (see the header of evz_sift.cpp) */
+int evo_sift_layout(int w, int h, int* ow, int* oh, int cap);
+int64_t evo_sift_gauss_pyramid(const uint8_t* gray, int w, int h, float* out, int64_t cap);
+int evo_sift_detect(const uint8_t* gray, int w, int h, float* xy, uint8_t* desc, int* octave, float* size, float* angle,
+                    float* response, int cap);
+float evo_sift_exp32f(float x);
+float evo_sift_exp2(float x);
+/* BruteForce 2-NN on float32 descriptors (matching.py:102-108 for SIFT / SURF): idx i32[nq,2], dist f32[nq,2] */
+void evo_knn2_l2f32(const float* q, int nq, const float* t, int nt, int dim, int32_t* idx, float* dist);
+int evo_ratio_unique_f32(const int32_t* idx, const float* dist, int nq, double ratio, int32_t* out_q, int32_t* out_t);
+int evo_match_static_f32(const float* xy_a, const float* desc_a, int na, const float* xy_b, const float* desc_b, int nb,
+                         int dim, float* oa, float* ob, int* out_n);
+/* one stream with a LIST of feature types (0 = ORB, 1 = SIFT), frame_processing.py:91-104 + video_processing.py:67-105 */
+int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types, int ntypes,
+                          double* H, int* status);
+
 /* ---- K7 + glue: matching (matching.py:75-129, 166-239; utils.py:41-68) ---- */
 void evo_knn2_l2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, uint32_t* d2);
 void evo_knn2_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, uint32_t* d2);

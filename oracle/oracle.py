@@ -266,3 +266,87 @@ def stream_gray(frames, nfeatures=500, force_max_iters=False):
     H = np.zeros((nf - 1, 9), np.float64); st = np.zeros(nf - 1, np.int32)
     rc = lib().evo_stream_gray_ex(_p(frames), nf, w, h, nfeatures, int(bool(force_max_iters)), _p(H), _p(st))
     return H.reshape(-1, 3, 3), st, rc
+
+
+# ---- N4: SIFT (oracle/evz_sift.cpp; restated from recall, parity unpinned) -------------------------------------------
+def sift_layout(w, h):
+    ow = np.zeros(16, np.int32); oh = np.zeros(16, np.int32)
+    n = lib().evo_sift_layout(int(w), int(h), _p(ow), _p(oh), 16)
+    return [(int(ow[o]), int(oh[o])) for o in range(n)]
+
+
+def sift_gauss_pyramid(gray):
+    """-> list over octaves of float32[6, h_o, w_o] (the Gaussian scale space of SIFT_create().detectAndCompute)."""
+    gray = _u8(gray)
+    h, w = gray.shape
+    lay = sift_layout(w, h)
+    total = sum(6 * a * b for a, b in lay)
+    buf = np.zeros(total, np.float32)
+    f = lib().evo_sift_gauss_pyramid
+    f.restype = C.c_int64
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    n = f(_p(gray), w, h, _p(buf), total)
+    assert n == total
+    out, off = [], 0
+    for (a, b) in lay:
+        out.append(buf[off:off + 6 * a * b].reshape(6, b, a))
+        off += 6 * a * b
+    return out
+
+
+def sift_detect(gray, cap=20000):
+    """-> dict(xy f32[N,2], desc f32[N,128] (integer values 0..255, as the operator returns them), octave i32[N] (packed
+    octave | layer << 8 | ...), size, angle, response), in the operator's own order (removeDuplicatedSorted)."""
+    gray = _u8(gray)
+    h, w = gray.shape
+    xy = np.zeros((cap, 2), np.float32); desc = np.zeros((cap, 128), np.uint8); oc = np.zeros(cap, np.int32)
+    sz = np.zeros(cap, np.float32); an = np.zeros(cap, np.float32); rs = np.zeros(cap, np.float32)
+    n = lib().evo_sift_detect(_p(gray), w, h, _p(xy), _p(desc), _p(oc), _p(sz), _p(an), _p(rs), cap)
+    assert n <= cap, "raise cap"
+    return dict(xy=xy[:n].copy(), desc=desc[:n].astype(np.float32), octave=oc[:n].copy(), size=sz[:n].copy(),
+                angle=an[:n].copy(), response=rs[:n].copy())
+
+
+def knn2_f32(q, t):
+    """BruteForce knnMatch(q, t, 2) on float32 descriptors -> (idx i32[nq,2], dist f32[nq,2])."""
+    q = _f32(q); t = _f32(t)
+    dim = q.shape[1]
+    idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.float32)
+    lib().evo_knn2_l2f32(_p(q), len(q), _p(t), len(t), dim, _p(idx), _p(dist))
+    return idx, dist
+
+
+def ratio_unique_f32(idx, dist, ratio=0.5):
+    idx = np.ascontiguousarray(idx, np.int32); dist = _f32(dist)
+    n = len(idx)
+    oq = np.zeros(max(n, 1), np.int32); ot = np.zeros(max(n, 1), np.int32)
+    f = lib().evo_ratio_unique_f32
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    m = f(_p(idx), _p(dist), n, float(ratio), _p(oq), _p(ot))
+    return oq[:m].copy(), ot[:m].copy()
+
+
+def match_static_f32(xy_a, desc_a, xy_b, desc_b):
+    """KeyPoints(a).match_static_kps(KeyPoints(b)) on float descriptors -> (status, pts_a, pts_b)"""
+    xy_a = _f32(xy_a).reshape(-1, 2); xy_b = _f32(xy_b).reshape(-1, 2)
+    desc_a = _f32(desc_a); desc_b = _f32(desc_b)
+    na = len(xy_a)
+    dim = desc_a.shape[1] if desc_a.ndim == 2 and na else (desc_b.shape[1] if desc_b.ndim == 2 else 128)
+    oa = np.zeros((max(na, 1), 2), np.float32); ob = np.zeros((max(na, 1), 2), np.float32)
+    n = C.c_int(0)
+    st = lib().evo_match_static_f32(_p(xy_a), _p(desc_a), na, _p(xy_b), _p(desc_b), len(xy_b), int(dim), _p(oa), _p(ob),
+                                    C.byref(n))
+    return st, oa[:n.value].copy(), ob[:n.value].copy()
+
+
+FEATURE_CODES = {"ORB": 0, "SIFT": 1}
+
+
+def stream_gray_types(frames, features, nfeatures=500):
+    """frames u8[F,h,w], features e.g. ["SIFT", "ORB"] -> (H f64[F-1,3,3], status i32[F-1], failed_first_pair_index or -1)"""
+    frames = _u8(frames)
+    nf, h, w = frames.shape
+    t = np.ascontiguousarray([FEATURE_CODES[f] for f in features], np.int32)
+    H = np.zeros((nf - 1, 9), np.float64); st = np.zeros(nf - 1, np.int32)
+    rc = lib().evo_stream_gray_types(_p(frames), nf, w, h, nfeatures, _p(t), len(t), _p(H), _p(st))
+    return H.reshape(-1, 3, 3), st, rc
