@@ -1,9 +1,10 @@
 """Per-frame feature extraction -- MI355X counterpart of evenvizion/processing/frame_processing.py.
 
 FrameProcessing.detect_and_describe_features("ORB") (frame_processing.py:59-61, 70-71) runs the HIP ORB
-(evh_orb_detect_batch).  The reference's default feature list is ["SURF", "SIFT", "ORB"] (frame_processing.py:40);
-SIFT and SURF (non-free opencv-contrib detectors) are outside this path: the default here is ["ORB"] and asking
-for the other two raises NotImplementedError.
+(evh_orb_detect_batch), "SIFT" (frame_processing.py:62-64) the HIP SIFT (evh_sift_detect_batch): coordinates float32[N,2]
+and descriptors uint8[N,32] / float32[N,128] exactly as cv2 hands them over.  The reference's default feature list is
+["SURF", "SIFT", "ORB"] (frame_processing.py:40); SURF is not built, so the default here is DEFAULT_FEATURES = ["ORB"]
+(the north-star path) and "SURF" raises NotImplementedError.
 """
 import numpy as np
 
@@ -12,11 +13,14 @@ from .matching import KeyPoints, NoMatchesException
 from .utils import remove_double_matching
 
 
+DEFAULT_FEATURES = ["ORB"]
+
+
 class FrameProcessing:
     def __init__(self, frame, features_type_list=None):
         self.isv3 = True
         self.frame = frame
-        self.features_types = features_type_list or ["ORB"]
+        self.features_types = features_type_list or list(DEFAULT_FEATURES)
         self._cache = {}
 
     def detect_and_describe_features(self, features_name):
@@ -30,9 +34,19 @@ class FrameProcessing:
                 f = ctx.orb_download(0)
                 self._cache["ORB"] = (f["xy"], f["desc"] if len(f["xy"]) else None)
             return self._cache["ORB"]
-        if features_name in ("SIFT", "SURF"):
-            raise NotImplementedError("%s is outside the MI355X hot path (non-free opencv-contrib detector); "
-                                      "use features_type_list=['ORB']" % features_name)
+        if features_name == "SIFT":
+            if "SIFT" not in self._cache:
+                frame = np.ascontiguousarray(self.frame, np.uint8)
+                h, w = frame.shape[:2]
+                ctx = runtime.get_context(w, h, 2, runtime.NFEATURES, sift=True)
+                d_frame = runtime.to_device(frame[None])
+                ctx.sift_detect_batch(d_frame)
+                f = ctx.sift_download(0)               # synchronises: d_frame may go
+                del d_frame
+                self._cache["SIFT"] = (f["xy"], f["desc"] if len(f["xy"]) else None)
+            return self._cache["SIFT"]
+        if features_name == "SURF":
+            raise NotImplementedError("SURF is not built on the MI355X path; use features_type_list=['SIFT', 'ORB'] or ['ORB']")
         raise ValueError("You need to choose descriptors type")
 
     def concatenate_all_features_types(self, acceding_image):

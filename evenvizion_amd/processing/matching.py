@@ -1,6 +1,7 @@
 """Key-point matching -- MI355X counterpart of evenvizion/processing/matching.py (same names, arguments, errors).
 
-KeyPoints.match_kps        : matching.py:75-129  -> evh_match_knn2_l2u8 + evh_ratio_unique_filter (HIP)
+KeyPoints.match_kps        : matching.py:75-129  -> evh_match_knn2_l2u8 (uint8 rows) / evh_match_knn2_l2f32 (float rows)
+                                                    + evh_ratio_unique_filter[_f32] (HIP)
 KeyPoints.match_static_kps : matching.py:131-163 -> + evh_find_homography_ransac + evh_static_filter (HIP)
 lowes_ratio_test / filter_corresponding_points : matching.py:166-239, host glue on DMatch-like objects, kept for
 API compatibility (the GPU path applies the same rules on device inside evh_ratio_unique_filter).
@@ -25,7 +26,7 @@ class NoMatchesException(Exception):
 
 
 class KeyPoints:
-    """coordinates: float32[N,2]; descriptors: uint8[N,32] or None (matching.py:47-73)."""
+    """coordinates: float32[N,2]; descriptors: uint8[N,32] (ORB), float32[N,128] (SIFT) or None (matching.py:47-73)."""
 
     def __init__(self, coordinates, descriptors):
         self.coordinates = coordinates
@@ -37,8 +38,14 @@ class KeyPoints:
             raise NoMatchesException("self.descriptors is None", "couldn't process")
         if acceding_kps.descriptors is None:
             raise NoMatchesException("kps.descriptors is None", "couldn't process")
-        q = np.ascontiguousarray(self.descriptors, np.uint8).reshape(-1, 32)
-        t = np.ascontiguousarray(acceding_kps.descriptors, np.uint8).reshape(-1, 32)
+        float_desc = np.asarray(self.descriptors).dtype != np.uint8       # SIFT / SURF rows (float32), ORB rows are uint8
+        if float_desc:
+            q = np.ascontiguousarray(self.descriptors, np.float32)
+            t = np.ascontiguousarray(acceding_kps.descriptors, np.float32)
+            q = q.reshape(len(q), -1); t = t.reshape(len(t), -1)
+        else:
+            q = np.ascontiguousarray(self.descriptors, np.uint8).reshape(-1, 32)
+            t = np.ascontiguousarray(acceding_kps.descriptors, np.uint8).reshape(-1, 32)
         xy_q = np.ascontiguousarray(self.coordinates, np.float32).reshape(-1, 2)
         xy_t = np.ascontiguousarray(acceding_kps.coordinates, np.float32).reshape(-1, 2)
         nq, nt = len(q), len(t)
@@ -47,14 +54,18 @@ class KeyPoints:
         ctx = runtime.get_context(64, 64, 2, max(nq, nt, runtime.NFEATURES))
         dev = runtime.device()
         idx = torch.empty(nq, 2, dtype=torch.int32, device=dev)
-        d2 = torch.empty(nq, 2, dtype=torch.int32, device=dev)
+        d2 = torch.empty(nq, 2, dtype=torch.float32 if float_desc else torch.int32, device=dev)
         pts = torch.empty(nq, 4, dtype=torch.float32, device=dev)
         # all four uploads live in named locals until ratio_unique_filter (which synchronises the context's stream)
         # has returned: a temporary freed right after an asynchronous launch could be handed to the next upload by
         # torch's caching allocator while the kernel is still reading it
         d_q, d_t, d_xy_q, d_xy_t = (runtime.to_device(a) for a in (q, t, xy_q, xy_t))
-        ctx.knn2(d_q, d_t, idx, d2)
-        n, st = ctx.ratio_unique_filter(idx, d2, d_xy_q, d_xy_t, pts, ratio=ratio, min_matches=min_matching_pts)
+        if float_desc:           # matching.py:102-108 on float32[N,64|128]: evh_match_knn2_l2f32
+            ctx.knn2_f32(d_q, d_t, idx, d2)
+            n, st = ctx.ratio_unique_filter_f32(idx, d2, d_xy_q, d_xy_t, pts, ratio=ratio, min_matches=min_matching_pts)
+        else:
+            ctx.knn2(d_q, d_t, idx, d2)
+            n, st = ctx.ratio_unique_filter(idx, d2, d_xy_q, d_xy_t, pts, ratio=ratio, min_matches=min_matching_pts)
         ctx.order_torch_after()
         del d_q, d_t, d_xy_q, d_xy_t
         if st == PAIR_FEW_MATCHES:

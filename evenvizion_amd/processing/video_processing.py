@@ -27,8 +27,10 @@ def resized_shape(frame_shape, resize_width):
 
 
 def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_processing=True,
-                        nfeatures=runtime.NFEATURES, chunk_frames=CHUNK_FRAMES):
-    """capture: anything with read() -> (bool, BGR uint8 frame) (cv2.VideoCapture duck type)."""
+                        nfeatures=runtime.NFEATURES, chunk_frames=CHUNK_FRAMES, features_type_list=None):
+    """capture: anything with read() -> (bool, BGR uint8 frame) (cv2.VideoCapture duck type).
+    features_type_list: the list the reference hands to FrameProcessing (frame_processing.py:37-40), e.g. ["SIFT", "ORB"];
+    None = frame_processing.DEFAULT_FEATURES (["ORB"]: the reference's own default also runs SURF, which is not built)."""
     import torch
     if matching_path:
         raise NotImplementedError("matching visualisation (draw_matches + imwrite) is outside the MI355X hot path; "
@@ -41,10 +43,18 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     cn = 1 if first.ndim == 2 else first.shape[2]
     dw, dh = resized_shape(first.shape, resize_width)
     # one staging buffer (pinned host / device) is capped in bytes: 4K BGR frames give 21-frame chunks, not 64
+    from .frame_processing import DEFAULT_FEATURES
+    features = list(features_type_list or DEFAULT_FEATURES)
+    for name in features:
+        if name == "SURF":
+            raise NotImplementedError("SURF is not built on the MI355X path; use features_type_list=['SIFT', 'ORB'] or ['ORB']")
+        if name not in ("ORB", "SIFT"):
+            raise ValueError("You need to choose descriptors type")
+    multi = features != ["ORB"]
     chunk_frames = runtime.chunk_frames_for(first.nbytes, max(2, int(chunk_frames)))
     # sized for the RESIZED frames: only those go through ORB (evh_resize_area_u8 does not depend on the context's
     # geometry), so a 4K source with resize_width=400 allocates 400-wide buffers
-    ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures)
+    ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures, sift="SIFT" in features)
     dev = runtime.device()
     # Double-buffered chunk pipeline: while the GPU works on chunk i the host reads chunk i+1 from the capture into
     # pinned memory and its upload runs on a copy stream; results come back through pinned buffers.  Chunk i is
@@ -65,8 +75,13 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     frame_no = [1]          # 1-based index of the newest frame already paired
 
     def launch(c, jb, nb, with_state):
-        c.stream_homography_batch(devbuf[jb][:nb], H_dev[jb], st_dev[jb], state_in=state if with_state else None,
-                                  state_out=state, nfeatures=nfeatures, resize_to=(dw, dh))
+        if multi:       # frame_processing.py:91-104 over the type list: evh_stream_homography_batch_types
+            c.stream_homography_batch_types(devbuf[jb][:nb], H_dev[jb], st_dev[jb], features,
+                                            state_in=state if with_state else None, state_out=state, nfeatures=nfeatures,
+                                            resize_to=(dw, dh))
+        else:
+            c.stream_homography_batch(devbuf[jb][:nb], H_dev[jb], st_dev[jb], state_in=state if with_state else None,
+                                      state_out=state, nfeatures=nfeatures, resize_to=(dw, dh))
         if cuda:
             c.order_torch_after()
         H_host[jb][:nb - 1].copy_(H_dev[jb][:nb - 1], non_blocking=True)
@@ -89,9 +104,11 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
             try:
                 big = Context(device=runtime.device_index(), max_w=max(dw, 64), max_h=max(dh, 64), max_features=feats,
                               max_frames=chunk_frames)
+                if "SIFT" in features:
+                    big.sift_enable(runtime.SIFT_FEATURES)
             except EvhError:
-                raise EvhError("frame %d..%d: more tied key points than the largest frame slot this device path "
-                               "supports" % (frame_no[0], frame_no[0] + nb - 1))
+                raise EvhError("frame %d..%d: more key points (ORB ties at the retainBest cut, or SIFT key points) than "
+                               "the largest frame slot this device path supports" % (frame_no[0], frame_no[0] + nb - 1))
             try:
                 state.copy_(state_pre[jb])
                 launch(big, jb, nb, had_state[jb])

@@ -10,14 +10,17 @@ from . import _lib
 _ctx = None
 _cfg = None
 NFEATURES = 500  # cv2.ORB_create() default used by the reference (frame_processing.py:60)
+SIFT_FEATURES = 6144  # SIFT key points reserved per frame slot (SIFT_create() keeps every key point; a textured 400x224
+                      # frame has ~2 500).  The matching filter bounds it at 7 680 - ORB's slot (evh_sift_enable).
 
 
 def device_index():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def get_context(w, h, nframes=2, nfeatures=NFEATURES):
-    """A context able to hold `nframes` frames of w x h with `nfeatures` keypoints each."""
+def get_context(w, h, nframes=2, nfeatures=NFEATURES, sift=False):
+    """A context able to hold `nframes` frames of w x h with `nfeatures` keypoints each (sift=True: with the SIFT buffers,
+    evh_sift_enable)."""
     global _ctx, _cfg
     import torch
     if not torch.cuda.is_available():
@@ -30,6 +33,8 @@ def get_context(w, h, nframes=2, nfeatures=NFEATURES):
             _ctx.close()
         _ctx = _lib.Context(device=device_index(), max_w=cfg[0], max_h=cfg[1], max_features=cfg[3], max_frames=cfg[2])
         _cfg = cfg
+    if sift and _ctx.lib.evh_sift_capacity(_ctx.h) <= 0:
+        _ctx.sift_enable(SIFT_FEATURES)
     return _ctx
 
 

@@ -186,3 +186,41 @@ def test_multi_type_independent_pairs_and_bgr():
             assert np.allclose(Hg[p], Ho[0], rtol=1e-9, atol=1e-12)
     finally:
         c.close()
+
+
+def test_python_mirror_sift_and_type_list():
+    """FrameProcessing(frame, ["SIFT", "ORB"]) / KeyPoints on float descriptors / get_homography_dict(features_type_list=)
+    -- the reference's API with its own argument (frame_processing.py:37-108, matching.py:75-163) -- against the oracle."""
+    from evenvizion_amd import runtime
+    from evenvizion_amd.processing import FrameProcessing, KeyPoints, get_homography_dict, compute_homography
+    runtime.reset()
+    w, h = 400, 224
+    frames, _ = S.make_stream(37, 5, w, h)
+    bgr = [S.gray_to_bgr(f) for f in frames]
+    fa, fb = FrameProcessing(bgr[1], ["SIFT", "ORB"]), FrameProcessing(bgr[0], ["SIFT", "ORB"])
+    xy, desc = fa.detect_and_describe_features("SIFT")
+    o1, o0 = O.sift_detect(frames[1]), O.sift_detect(frames[0])
+    assert xy.dtype == np.float32 and desc.dtype == np.float32 and desc.shape[1] == 128
+    assert np.array_equal(xy, o1["xy"]) and np.array_equal(desc, o1["desc"])
+    with pytest.raises(NotImplementedError):
+        fa.detect_and_describe_features("SURF")
+    # KeyPoints on float descriptors: match_kps / match_static_kps
+    pa, pb = KeyPoints(o1["xy"], o1["desc"]).match_kps(KeyPoints(o0["xy"], o0["desc"]))
+    oi, od = O.knn2_f32(o1["desc"], o0["desc"])
+    mq, mt = O.ratio_unique_f32(oi, od)
+    wa, wb = O.remove_double(o1["xy"][mq], o0["xy"][mt])
+    assert np.array_equal(np.array(pa), wa) and np.array_equal(np.array(pb), wb)
+    sa, sb = KeyPoints(o1["xy"], o1["desc"]).match_static_kps(KeyPoints(o0["xy"], o0["desc"]))
+    st, ea, eb = O.match_static_f32(o1["xy"], o1["desc"], o0["xy"], o0["desc"])
+    assert st == 0 and np.array_equal(sa, ea) and np.array_equal(sb, eb)
+    # the per-pair body over both types, then compute_homography
+    ca, cb = fa.concatenate_all_features_types(fb)
+    H = compute_homography(ca, cb, None)
+    Ho, so, rc = O.stream_gray_types(frames[:2], ["SIFT", "ORB"])
+    assert rc == -1 and so[0] == 0 and np.allclose(H, Ho[0], rtol=1e-9, atol=1e-12)
+    # the stream driver with a type list (chunked)
+    Hs, ss, rc = O.stream_gray_types(frames, ["SIFT", "ORB"])
+    d = get_homography_dict(S.SyntheticCapture(bgr), resize_width=w, chunk_frames=3, features_type_list=["SIFT", "ORB"])
+    got = np.array([d[k]["H"] for k in range(2, len(frames) + 1)])
+    assert rc == -1 and (ss == 0).all() and np.allclose(got, Hs, rtol=1e-9, atol=1e-12)
+    runtime.reset()

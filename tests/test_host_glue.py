@@ -124,6 +124,10 @@ class _FakeCtx:
     def resize_area(self, src, dst):
         dst.copy_(src[:, :dst.shape[1], :dst.shape[2]])
 
+    def stream_homography_batch_types(self, frames, H, st, features, **kw):
+        self.types_calls = getattr(self, "types_calls", 0) + 1
+        return self.stream_homography_batch(frames, H, st, **kw)
+
     def stream_homography_batch(self, frames, H, st, state_in=None, state_out=None, nfeatures=500, **kw):
         ids = frames[:, 0, 0, 0].tolist()
         self.calls.append((ids, state_in is not None))
@@ -170,6 +174,14 @@ def test_driver_loop_matches_reference(goldens, monkeypatch, chunk):
         video_processing.get_homography_dict(_Cap(0))
     with pytest.raises(NotImplementedError):
         video_processing.get_homography_dict(_Cap(3), matching_path="/tmp/x")
+    with pytest.raises(NotImplementedError):
+        video_processing.get_homography_dict(_Cap(3), features_type_list=["SURF", "SIFT", "ORB"])
+    with pytest.raises(ValueError):
+        video_processing.get_homography_dict(_Cap(3), features_type_list=["BRISK"])
+    fake = _FakeCtx({"1": np.eye(3).tolist(), "2": np.eye(3).tolist()})
+    monkeypatch.setattr(runtime, "get_context", lambda *a, **k: fake)
+    res = video_processing.get_homography_dict(_Cap(3), resize_width=8, chunk_frames=chunk, features_type_list=["SIFT", "ORB"])
+    assert fake.types_calls >= 1 and sorted(k for k in res if k != "resize_info") == [2, 3]
 
 
 def test_install_as_evenvizion_keeps_the_real_package_reachable(tmp_path, monkeypatch):
