@@ -729,7 +729,7 @@ def test_python_api_mirror_vs_oracle():
     with pytest.raises(ValueError):
         fa.detect_and_describe_features("BRISK")
     with pytest.raises(NotImplementedError):
-        fa.detect_and_describe_features("SIFT")
+        fa.detect_and_describe_features("SURF")
     pa, pb = fa.concatenate_all_features_types(fb)
     ob = O.orb_detect(frames[0])
     st, sa, sb = O.match_static(o["xy"], o["desc"], ob["xy"], ob["desc"])
