@@ -73,6 +73,12 @@ SIGNATURES = {
     "evh_sift_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evh_sift_octave_info": (_i, [_vp, _i, _pi, _pi]),
     "evh_sift_download_gauss": (_i, [_vp, _i, _i, _i, _vp]),
+    "evh_surf_enable": (_i, [_vp, _i]),
+    "evh_surf_capacity": (_i, [_vp]),
+    "evh_surf_detect_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _d]),
+    "evh_surf_count": (_i, [_vp, _i]),
+    "evh_surf_download": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evh_surf_download_integral": (_i, [_vp, _i, _vp]),
     "evh_match_knn2_l2f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "evh_ratio_unique_filter_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _i, _vp, _pi, _pi]),
     "evh_pair_homography_batch_types": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _vp, _i, _d, _i, _d, _i, _vp, _vp]),
@@ -394,6 +400,34 @@ class Context:
         self._check(self.lib.evh_sift_download_gauss(self.h, frame, octave, layer, _hp(out)))
         return out
 
+    def surf_enable(self, max_surf_features=4096):
+        self._check(self.lib.evh_surf_enable(self.h, int(max_surf_features)))
+
+    def surf_detect_batch(self, frames, resize_to=None, hessian_threshold=400.0):
+        """frames: CUDA uint8 [n,h,w] or [n,h,w,3]; SURF_create(extended=1, hessianThreshold=400).detectAndCompute
+        (frame_processing.py:65-67)."""
+        self._enter()
+        n, h, w = frames.shape[:3]
+        cn = 1 if frames.dim() == 3 else frames.shape[3]
+        dw, dh = (w, h) if resize_to is None else (int(resize_to[0]), int(resize_to[1]))
+        self._surf_shape = (dh, dw)
+        self._check(self.lib.evh_surf_detect_batch(self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, dw, dh,
+                                                   float(hessian_threshold)))
+
+    def surf_download(self, frame):
+        cap = self.lib.evh_surf_capacity(self.h)
+        xy = np.zeros((cap, 2), np.float32); desc = np.zeros((cap, 128), np.float32); sz = np.zeros(cap, np.float32)
+        an = np.zeros(cap, np.float32); rs = np.zeros(cap, np.float32); oc = np.zeros(cap, np.int32); lp = np.zeros(cap, np.int32)
+        n = self._check(self.lib.evh_surf_download(self.h, frame, _hp(xy), _hp(desc), _hp(sz), _hp(an), _hp(rs), _hp(oc), _hp(lp)))
+        return dict(xy=xy[:n].copy(), desc=desc[:n].copy(), size=sz[:n].copy(), angle=an[:n].copy(), response=rs[:n].copy(),
+                    octave=oc[:n].copy(), laplacian=lp[:n].copy())
+
+    def surf_download_integral(self, frame):
+        h, w = self._surf_shape
+        out = np.zeros((h + 1, w + 1), np.int32)
+        self._check(self.lib.evh_surf_download_integral(self.h, frame, _hp(out)))
+        return out
+
     def knn2_f32(self, q, t, idx, dist):
         """q, t: CUDA float32 [n,dim] (dim 64 or 128); idx int32 [nq,2], dist float32 [nq,2]."""
         self._enter()
@@ -420,6 +454,7 @@ class Context:
         cn = 1 if frames.dim() == 3 else frames.shape[3]
         dw, dh = (w, h) if resize_to is None else (int(resize_to[0]), int(resize_to[1]))
         t = self._types(features)
+        self._multi_used = True
         self._check(self.lib.evh_pair_homography_batch_types(
             self.h, frames.data_ptr(), npairs, mode, w, h, cn, w * cn, w * h * cn, dw, dh, nfeatures, _hp(t), len(t), float(thr),
             int(max_iters), float(conf), int(bool(force_max_iters)), out_H.data_ptr(), out_status.data_ptr()))
@@ -433,6 +468,7 @@ class Context:
         cn = 1 if frames.dim() == 3 else frames.shape[3]
         dw, dh = (w, h) if resize_to is None else (int(resize_to[0]), int(resize_to[1]))
         t = self._types(features)
+        self._multi_used = True
         self._check(self.lib.evh_stream_homography_batch_types(
             self.h, frames.data_ptr(), n, w, h, cn, w * cn, w * h * cn, dw, dh, nfeatures, _hp(t), len(t), float(thr),
             int(max_iters), float(conf), int(bool(force_max_iters)), state_in.data_ptr() if state_in is not None else None,

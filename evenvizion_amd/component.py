@@ -53,6 +53,8 @@ def main(argv=None):
     ap.add_argument("--none_H_processing", default=True, help="If True use H_prev as H, False - do nothing")
     ap.add_argument("--heatmap_visualization", default=True, help="write metrics_file.txt (pictures are not rendered)")
     ap.add_argument("--show_matching_visualization", default=False, help="not available: matching pictures are not rendered")
+    ap.add_argument("--features", type=str, default="SURF,SIFT,ORB",
+                    help="feature types in FrameProcessing order (extension; the reference hard-wires SURF,SIFT,ORB)")
     args = ap.parse_args(argv)
     if _bool(args.show_matching_visualization):
         raise NotImplementedError("matching pictures are outside the MI355X hot path; leave --show_matching_visualization off")
@@ -70,7 +72,8 @@ def main(argv=None):
     os.makedirs(save_folder, exist_ok=True)
 
     result = get_homography_dict(SyntheticCapture(frames), resize_width=args.resize_width, matching_path=None,
-                                 none_H_processing=_bool(args.none_H_processing))
+                                 none_H_processing=_bool(args.none_H_processing),
+                                 features_type_list=[f for f in args.features.split(",") if f])
     path_to_homography_dict = os.path.join(save_folder, "dict_with_homography_matrix.json")
     with open(path_to_homography_dict, "w") as json_:
         json.dump(result, json_)

@@ -271,8 +271,8 @@ int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int s
 // ---- multi-type pairs (frame_processing.py:91-104) ---------------------------------------------------------------------------
 int ensure_multitype(evh_ctx* c) {
   if (c->mt.cap) return EVH_SUCCESS;
-  if (!c->sift_cap) return evh_fail(c, EVH_ERR_INVALID, "feature types beyond ORB need evh_sift_enable first");
-  const int each = std::max(c->kcap, c->sift_cap), cap = c->kcap + c->sift_cap;
+  if (!c->sift_cap && !c->surf_cap) return evh_fail(c, EVH_ERR_INVALID, "feature types beyond ORB need evh_sift_enable / evh_surf_enable first");
+  const int each = std::max(c->kcap, std::max(c->sift_cap, c->surf_cap)), cap = c->kcap + c->sift_cap + c->surf_cap;
   if ((size_t)each * 5 * sizeof(int) > 150 * 1024)
     return evh_fail(c, EVH_ERR_CAPACITY, "multi-type pairs: at most 7680 key points per frame and type in the matching filter");
   const size_t P = (size_t)c->max_frames, K = (size_t)cap;
@@ -311,26 +311,36 @@ EvhRansacArgs mt_ransac_args(evh_ctx* c, double thr, int max_iters, double conf,
 // K7 + glue of ONE feature type into the multi-type pair buffers
 int match_pairs_type(evh_ctx* c, int type, int npairs, int q0, int qstep, int t0, int tstep) {
   const EvhPairBufs& B = c->mt;
-  const bool sift = type == EVH_FEATURE_SIFT;
-  EvhKnnArgs K{};
-  K.q = sift ? c->d_sift_desc : c->d_desc; K.t = K.q;
-  K.slot_bytes = sift ? (int64_t)c->sift_cap * 128 : (int64_t)c->kcap * 32;
-  K.desc_bytes = sift ? 128 : 32;
-  const int* counts = sift ? c->d_sift_count : c->d_kp_count;
-  K.nq_arr = counts; K.nt_arr = counts;
-  K.q_slot0 = q0; K.q_slot_step = qstep; K.t_slot0 = t0; K.t_slot_step = tstep;
-  K.idx = B.knn_idx; K.d2 = B.knn_d2; K.out_stride = B.cap; K.hamming = 0;
+  const bool sift = type == EVH_FEATURE_SIFT, surf = type == EVH_FEATURE_SURF;
+  const int* counts = sift ? c->d_sift_count : surf ? c->d_surf_count : c->d_kp_count;
+  const int tcap = sift ? c->sift_cap : surf ? c->surf_cap : c->kcap;
   int rc;
-  { EvhProfScope ps(c, EVH_ST_KNN); rc = evh_launch_knn2(c, K, npairs); }
+  if (surf) {            // real-valued float rows: the float matcher, distances carried as float bits
+    EvhKnnF32Args K{};
+    K.q = c->d_surf_desc; K.t = c->d_surf_desc; K.dim = 128; K.n_arr = counts; K.slot_floats = (int64_t)tcap * 128;
+    K.q_slot0 = q0; K.q_slot_step = qstep; K.t_slot0 = t0; K.t_slot_step = tstep;
+    K.idx = B.knn_idx; K.dist = reinterpret_cast<float*>(B.knn_d2); K.out_stride = B.cap;
+    { EvhProfScope ps(c, EVH_ST_KNN); rc = evh_launch_knn2_f32(c, K, npairs); }
+  } else {
+    EvhKnnArgs K{};
+    K.q = sift ? c->d_sift_desc : c->d_desc; K.t = K.q;
+    K.slot_bytes = sift ? (int64_t)tcap * 128 : (int64_t)tcap * 32;
+    K.desc_bytes = sift ? 128 : 32;
+    K.nq_arr = counts; K.nt_arr = counts;
+    K.q_slot0 = q0; K.q_slot_step = qstep; K.t_slot0 = t0; K.t_slot_step = tstep;
+    K.idx = B.knn_idx; K.d2 = B.knn_d2; K.out_stride = B.cap; K.hamming = 0;
+    { EvhProfScope ps(c, EVH_ST_KNN); rc = evh_launch_knn2(c, K, npairs); }
+  }
   if (rc) return rc;
   EvhFilterArgs F{};
-  F.idx = B.knn_idx; F.d2 = B.knn_d2; F.knn_stride = B.cap;
-  F.xy_q = sift ? c->d_sift_xy : c->d_kp_xy; F.xy_t = F.xy_q;
-  F.xy_slot_floats = sift ? (int64_t)c->sift_cap * 2 : (int64_t)c->kcap * 2;
-  F.nq_arr = counts; F.nt_arr = counts; F.flags_arr = sift ? c->d_sift_flags : c->d_frame_flags;
+  F.idx = B.knn_idx; F.d2 = B.knn_d2; F.knn_stride = B.cap; F.d2_is_dist = surf ? 1 : 0;
+  F.xy_q = sift ? c->d_sift_xy : surf ? c->d_surf_xy : c->d_kp_xy; F.xy_t = F.xy_q;
+  F.xy_slot_floats = (int64_t)tcap * 2;
+  F.nq_arr = counts; F.nt_arr = counts; F.flags_arr = sift ? c->d_sift_flags : surf ? c->d_surf_flags : c->d_frame_flags;
   F.q_slot0 = q0; F.q_slot_step = qstep; F.t_slot0 = t0; F.t_slot_step = tstep;
   F.ratio = 0.5; F.min_matches = 4;
-  F.pts = B.pts; F.pts_stride = B.cap; F.npts = B.npts; F.status = B.pstatus; F.kcap = std::max(c->kcap, c->sift_cap);
+  F.pts = B.pts; F.pts_stride = B.cap; F.npts = B.npts; F.status = B.pstatus;
+  F.kcap = std::max(c->kcap, std::max(c->sift_cap, c->surf_cap));
   EvhProfScope ps(c, EVH_ST_FILTER);
   return evh_launch_filter(c, F, npairs);
 }
@@ -342,13 +352,17 @@ int pairs_types(evh_ctx* c, const char* who, const uint8_t* d_frames, int nframe
                 int ntypes, double thr, int max_iters, double conf, int force_max, const double* d_state_in, double* d_state_out,
                 double* d_H, int32_t* d_status) {
   if (!types || ntypes < 1 || ntypes > 8) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": bad feature type list");
-  bool want_orb = false, want_sift = false;
+  bool want_orb = false, want_sift = false, want_surf = false;
   for (int i = 0; i < ntypes; i++) {
     if (types[i] == EVH_FEATURE_ORB) want_orb = true;
     else if (types[i] == EVH_FEATURE_SIFT) want_sift = true;
-    else if (types[i] == EVH_FEATURE_SURF) return evh_fail(c, EVH_ERR_UNSUPPORTED, "SURF is not built (SURVEY 8f N4, second half)");
+    else if (types[i] == EVH_FEATURE_SURF) want_surf = true;
     else return evh_fail(c, EVH_ERR_INVALID, "unknown feature type");
   }
+  if (want_sift && !c->sift_cap) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": SIFT in the list needs evh_sift_enable");
+  if (want_surf && !c->surf_cap) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": SURF in the list needs evh_surf_enable");
+  if (c->mt.cap && c->mt.cap < c->kcap + c->sift_cap + c->surf_cap)
+    return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": enable SIFT and SURF before the first multi-type call");
   int rc = ensure_multitype(c);
   if (rc) return rc;
   if ((rc = join_solve(c))) return rc;
@@ -356,6 +370,7 @@ int pairs_types(evh_ctx* c, const char* who, const uint8_t* d_frames, int nframe
   c->fast_share_group = 0;
   if ((rc = ingest_level0(c, who, d_frames, nframes, sw, sh, w, h, channels, row_stride, frame_stride, nfeatures))) return rc;
   if (want_sift && (rc = evh_launch_sift(c, nframes, w, h))) return rc;       // reads level 0 before ORB's kernels run on it
+  if (want_surf && (rc = evh_launch_surf(c, nframes, w, h, 400.f))) return rc; // SURF_create(extended=1, hessianThreshold=400)
   if (want_orb && (rc = orb_stages(c, nframes, share_group))) return rc;
   const int q0 = 1, qstep = stream_mode ? 1 : 2, t0 = 0, tstep = stream_mode ? 1 : 2;
   EvhRansacArgs R = mt_ransac_args(c, thr, max_iters, conf, force_max);
@@ -475,6 +490,7 @@ void evh_destroy(evh_ctx* c) {
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   evh_sift_free(c);
+  evh_surf_free(c);
   {
     void* mp[] = {c->mt.knn_idx, c->mt.knn_d2, c->mt.pts, c->mt.pts2, c->mt.crow, c->mt.npts, c->mt.npts2, c->mt.pstatus, c->mt.H1,
                   c->mt.mask, c->mt.lm, c->mt.info, c->d_acc, c->d_nacc, c->d_accstatus};
@@ -1130,6 +1146,70 @@ int evh_stream_homography_batch_types(evh_ctx* c, const uint8_t* d_frames, int n
   return pairs_types(c, "evh_stream_homography_batch_types", d_frames, nframes, nframes - 1, 1, src_w, src_h, w, h, channels,
                      row_stride, frame_stride, nfeatures, h_types, ntypes, ransac_thr, ransac_max_iters, ransac_conf,
                      force_max_iters, d_state_in, d_state_out, d_H, d_status);
+}
+
+
+// ---- N4: SURF --------------------------------------------------------------------------------------------------------------------
+int evh_surf_enable(evh_ctx* c, int max_surf_features) {
+  if (!c) return EVH_ERR_INVALID;
+  return evh_surf_allocate(c, max_surf_features);
+}
+int evh_surf_capacity(const evh_ctx* c) { return c ? c->surf_cap : EVH_ERR_INVALID; }
+
+int evh_surf_detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                          int64_t row_stride, int64_t frame_stride, int w, int h, double hessian_threshold) {
+  if (!c) return EVH_ERR_INVALID;
+  if (!c->surf_cap) return evh_fail(c, EVH_ERR_INVALID, "evh_surf_detect_batch: call evh_surf_enable first");
+  if (!(hessian_threshold >= 0)) return evh_fail(c, EVH_ERR_INVALID, "evh_surf_detect_batch: hessian_threshold must be >= 0");
+  int rc = join_solve(c);
+  if (rc) return rc;
+  const int nf = c->geom_valid ? c->g.nfeatures : std::min(500, c->max_features);
+  if ((rc = ingest_level0(c, "evh_surf_detect_batch", d_frames, nframes, src_w, src_h, w, h, channels, row_stride, frame_stride, nf)))
+    return rc;
+  c->nframes_resident = 0;
+  return evh_launch_surf(c, nframes, w, h, (float)hessian_threshold);
+}
+
+int evh_surf_count(evh_ctx* c, int frame) {
+  if (!c || frame < 0 || frame >= c->surf_frames_resident) return evh_fail(c, EVH_ERR_INVALID, "bad SURF frame slot");
+  int n = 0, fl = 0;
+  EVH_HIP(c, hipMemcpyAsync(&n, c->d_surf_count + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipMemcpyAsync(&fl, c->d_surf_flags + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  if (fl) return evh_fail(c, EVH_ERR_CAPACITY, "more SURF key points than evh_surf_enable reserved for a frame");
+  return n;
+}
+
+int evh_surf_download(evh_ctx* c, int frame, float* h_xy, float* h_desc, float* h_size, float* h_angle, float* h_response,
+                      int32_t* h_octave, int32_t* h_laplacian) {
+  const int n = evh_surf_count(c, frame);
+  if (n <= 0) return n;
+  const size_t o = (size_t)frame * c->surf_cap;
+  std::vector<float> rec((size_t)n * 8);
+  EVH_HIP(c, hipMemcpyAsync(rec.data(), c->d_surf_kp + o * 8, sizeof(float) * 8 * n, hipMemcpyDeviceToHost, c->stream));
+  if (h_desc) EVH_HIP(c, hipMemcpyAsync(h_desc, c->d_surf_desc + o * 128, sizeof(float) * 128 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    const float* r = &rec[(size_t)i * 8];
+    if (h_xy) { h_xy[2 * i] = r[0]; h_xy[2 * i + 1] = r[1]; }
+    if (h_size) h_size[i] = r[2];
+    if (h_angle) h_angle[i] = r[3];
+    if (h_response) h_response[i] = r[4];
+    if (h_octave) memcpy(&h_octave[i], &r[5], 4);
+    if (h_laplacian) memcpy(&h_laplacian[i], &r[6], 4);
+  }
+  return n;
+}
+
+int evh_surf_download_integral(evh_ctx* c, int frame, int32_t* h_sum) {
+  if (!c || !h_sum || !c->surf_tab_w || frame < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_surf_download_integral: bad argument");
+  const int g0 = ((c->surf_frames_resident - 1) / c->surf_group) * c->surf_group;
+  if (frame < g0 || frame >= c->surf_frames_resident) return evh_fail(c, EVH_ERR_INVALID, "evh_surf_download_integral: that frame's integral image is no longer resident");
+  const int w = c->surf_tab_w, h = c->surf_tab_h, st = (w + 1 + 15) & ~15;
+  EVH_HIP(c, hipMemcpy2DAsync(h_sum, sizeof(int) * (w + 1), c->d_surf_sum + (int64_t)(frame - g0) * c->surf_sum_frame_ints, sizeof(int) * st,
+                              sizeof(int) * (w + 1), h + 1, hipMemcpyDeviceToHost, c->stream));
+  EVH_HIP(c, hipStreamSynchronize(c->stream));
+  return EVH_SUCCESS;
 }
 
 }  // extern "C"

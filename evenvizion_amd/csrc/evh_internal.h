@@ -127,8 +127,18 @@ struct evh_ctx {
   float* d_sift_xy = nullptr;     // [F][cap][2]
   uint8_t* d_sift_desc = nullptr; // [F][cap][128] descriptor VALUES (0..255; the operator returns them as float32)
   int* d_sift_count = nullptr; int* d_sift_flags = nullptr;
+  // ---- N4: SURF (allocated by evh_surf_enable) ----
+  int surf_cap = 0, surf_group = 0, surf_frames_resident = 0, surf_tab_w = 0, surf_tab_h = 0;
+  int64_t surf_sum_frame_ints = 0, surf_det_frame_floats = 0;
+  char* d_surf_tabs = nullptr;    // SurfTabs: layer boxes, orientation / descriptor weights
+  int* d_surf_sum = nullptr;      // [group] integral images, (h+1) x (w+1)
+  float* d_surf_det = nullptr; float* d_surf_trace = nullptr;   // [group] the 20 Hessian layers
+  float* d_surf_raw = nullptr; int* d_surf_nraw = nullptr; float* d_surf_srt = nullptr;
+  float* d_surf_kp = nullptr;     // [F][cap][8] x, y, size, angle, response, octave bits, laplacian bits
+  float* d_surf_xy = nullptr; float* d_surf_desc = nullptr;     // [F][cap][2], [F][cap][128] float
+  int* d_surf_count = nullptr; int* d_surf_flags = nullptr;
   // multi-type pairs (frame_processing.py:91-104): per-type match / static rows, their concatenation, the merged rows
-  EvhPairBufs mt;                 // stride mt.cap = kcap + sift_cap
+  EvhPairBufs mt;                 // stride mt.cap = kcap + sift_cap + surf_cap
   float* d_acc = nullptr; int* d_nacc = nullptr; int* d_accstatus = nullptr;
   size_t bytes_allocated = 0;
   std::string err;
@@ -173,6 +183,10 @@ int evh_launch_fixed_plane(evh_ctx* c, const double* d_H, int n, int w, int h, d
 int evh_sift_allocate(evh_ctx* c, int max_sift_features);
 void evh_sift_free(evh_ctx* c);
 int evh_launch_sift(evh_ctx* c, int nframes, int w, int h);
+// N4: SURF (evh_surf.hip)
+int evh_surf_allocate(evh_ctx* c, int max_surf_features);
+void evh_surf_free(evh_ctx* c);
+int evh_launch_surf(evh_ctx* c, int nframes, int w, int h, float hessian_threshold);
 int evh_launch_resize_area(evh_ctx* c, const uint8_t* d_src, int nimg, int sw, int sh, int cn, int64_t src_stride,
                            int64_t src_img_stride, uint8_t* d_dst, int dw, int dh, int64_t dst_stride,
                            int64_t dst_img_stride);

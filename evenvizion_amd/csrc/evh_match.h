@@ -32,7 +32,11 @@ struct EvhFilterArgs {
 };
 
 // BruteForce 2-NN on float32 descriptors (SIFT / SURF rows of `dim` floats, dim = 64 or 128)
-struct EvhKnnF32Args { const float* q; const float* t; int nq, nt, dim; int32_t* idx; float* dist; };
+struct EvhKnnF32Args {
+  const float* q; const float* t; int nq, nt, dim; int32_t* idx; float* dist;
+  // batched form (pairs of frame slots, like EvhKnnArgs): counts per slot, slot stride in floats, rows per pair in idx / dist
+  const int* n_arr; int64_t slot_floats; int q_slot0, q_slot_step, t_slot0, t_slot_step; int64_t out_stride;
+};
 
 // multi-type pairs (frame_processing.py:91-104): append one feature type's static rows, then remove_double_matching
 struct EvhAccArgs {
@@ -46,7 +50,7 @@ struct EvhMergeArgs {
 };
 
 struct evh_ctx;
-int evh_launch_knn2_f32(evh_ctx* c, const EvhKnnF32Args& A);
+int evh_launch_knn2_f32(evh_ctx* c, const EvhKnnF32Args& A, int npairs = 1);
 int evh_launch_accumulate(evh_ctx* c, const EvhAccArgs& A, int npairs);
 int evh_launch_merge(evh_ctx* c, const EvhMergeArgs& A, int npairs);
 int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs);

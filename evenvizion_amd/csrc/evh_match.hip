@@ -115,16 +115,27 @@ __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
 // and come through scalar loads.
 template <int DIM>
 __global__ __launch_bounds__(64) void k_knn2_f32(EvhKnnF32Args A) {
+  const int p = blockIdx.y;
+  int nq = A.nq, nt = A.nt;
+  const float* Qb = A.q; const float* Tb = A.t;
+  int32_t* oidx = A.idx; float* odist = A.dist;
+  if (A.n_arr) {
+    const int qs = A.q_slot0 + p * A.q_slot_step, ts = A.t_slot0 + p * A.t_slot_step;
+    nq = A.n_arr[qs]; nt = A.n_arr[ts];
+    Qb += (int64_t)qs * A.slot_floats; Tb += (int64_t)ts * A.slot_floats;
+    oidx += (int64_t)p * A.out_stride * 2; odist += (int64_t)p * A.out_stride * 2;
+  }
+  if ((int)blockIdx.x * 64 >= nq) return;
   const int qi = blockIdx.x * 64 + threadIdx.x;
-  const bool act = qi < A.nq;
+  const bool act = qi < nq;
   float q[DIM];
-  const float4* Q = reinterpret_cast<const float4*>(A.q + (int64_t)(act ? qi : 0) * DIM);
+  const float4* Q = reinterpret_cast<const float4*>(Qb + (int64_t)(act ? qi : 0) * DIM);
 #pragma unroll
   for (int k = 0; k < DIM / 4; k++) { const float4 v = Q[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
   float b0 = FLT_MAX, b1 = FLT_MAX;
   int i0 = -1, i1 = -1;
-  for (int j = 0; j < A.nt; j++) {
-    const float* t = A.t + (int64_t)j * DIM;
+  for (int j = 0; j < nt; j++) {
+    const float* t = Tb + (int64_t)j * DIM;
     float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < DIM; k += 8)
@@ -142,8 +153,8 @@ __global__ __launch_bounds__(64) void k_knn2_f32(EvhKnnF32Args A) {
     }
   }
   if (act) {
-    A.idx[2 * qi] = i0; A.idx[2 * qi + 1] = i1;
-    A.dist[2 * qi] = b0; A.dist[2 * qi + 1] = b1;
+    oidx[2 * qi] = i0; oidx[2 * qi + 1] = i1;
+    odist[2 * qi] = b0; odist[2 * qi + 1] = b1;
   }
 }
 
@@ -313,10 +324,12 @@ int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs) {
   return EVH_SUCCESS;
 }
 
-int evh_launch_knn2_f32(evh_ctx* c, const EvhKnnF32Args& A) {
-  if (A.nq <= 0) return EVH_SUCCESS;
-  if (A.dim == 128) hipLaunchKernelGGL(k_knn2_f32<128>, dim3((A.nq + 63) / 64), dim3(64), 0, c->stream, A);
-  else if (A.dim == 64) hipLaunchKernelGGL(k_knn2_f32<64>, dim3((A.nq + 63) / 64), dim3(64), 0, c->stream, A);
+int evh_launch_knn2_f32(evh_ctx* c, const EvhKnnF32Args& A, int npairs) {
+  const int nq_max = A.n_arr ? (int)A.out_stride : A.nq;
+  if (nq_max <= 0 || npairs <= 0) return EVH_SUCCESS;
+  const dim3 grid((nq_max + 63) / 64, npairs);
+  if (A.dim == 128) hipLaunchKernelGGL(k_knn2_f32<128>, grid, dim3(64), 0, c->stream, A);
+  else if (A.dim == 64) hipLaunchKernelGGL(k_knn2_f32<64>, grid, dim3(64), 0, c->stream, A);
   else return evh_fail(c, EVH_ERR_UNSUPPORTED, "float descriptors: 64 or 128 elements per row (SURF / SIFT)");
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;

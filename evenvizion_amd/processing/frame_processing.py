@@ -2,9 +2,10 @@
 
 FrameProcessing.detect_and_describe_features("ORB") (frame_processing.py:59-61, 70-71) runs the HIP ORB
 (evh_orb_detect_batch), "SIFT" (frame_processing.py:62-64) the HIP SIFT (evh_sift_detect_batch): coordinates float32[N,2]
-and descriptors uint8[N,32] / float32[N,128] exactly as cv2 hands them over.  The reference's default feature list is
-["SURF", "SIFT", "ORB"] (frame_processing.py:40); SURF is not built, so the default here is DEFAULT_FEATURES = ["ORB"]
-(the north-star path) and "SURF" raises NotImplementedError.
+"SURF" (frame_processing.py:65-67, SURF_create(extended=1, hessianThreshold=400)) the HIP SURF (evh_surf_detect_batch):
+coordinates float32[N,2] and descriptors uint8[N,32] / float32[N,128] exactly as cv2 hands them over.  The default
+feature list is the reference's own, ["SURF", "SIFT", "ORB"] (frame_processing.py:40); the north-star hot path is
+features_type_list=["ORB"].
 """
 import numpy as np
 
@@ -13,7 +14,7 @@ from .matching import KeyPoints, NoMatchesException
 from .utils import remove_double_matching
 
 
-DEFAULT_FEATURES = ["ORB"]
+DEFAULT_FEATURES = ["SURF", "SIFT", "ORB"]     # frame_processing.py:40
 
 
 class FrameProcessing:
@@ -46,7 +47,16 @@ class FrameProcessing:
                 self._cache["SIFT"] = (f["xy"], f["desc"] if len(f["xy"]) else None)
             return self._cache["SIFT"]
         if features_name == "SURF":
-            raise NotImplementedError("SURF is not built on the MI355X path; use features_type_list=['SIFT', 'ORB'] or ['ORB']")
+            if "SURF" not in self._cache:
+                frame = np.ascontiguousarray(self.frame, np.uint8)
+                h, w = frame.shape[:2]
+                ctx = runtime.get_context(w, h, 2, runtime.NFEATURES, surf=True)
+                d_frame = runtime.to_device(frame[None])
+                ctx.surf_detect_batch(d_frame)
+                f = ctx.surf_download(0)               # synchronises: d_frame may go
+                del d_frame
+                self._cache["SURF"] = (f["xy"], f["desc"] if len(f["xy"]) else None)
+            return self._cache["SURF"]
         raise ValueError("You need to choose descriptors type")
 
     def concatenate_all_features_types(self, acceding_image):

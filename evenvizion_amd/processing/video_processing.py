@@ -30,7 +30,8 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
                         nfeatures=runtime.NFEATURES, chunk_frames=CHUNK_FRAMES, features_type_list=None):
     """capture: anything with read() -> (bool, BGR uint8 frame) (cv2.VideoCapture duck type).
     features_type_list: the list the reference hands to FrameProcessing (frame_processing.py:37-40), e.g. ["SIFT", "ORB"];
-    None = frame_processing.DEFAULT_FEATURES (["ORB"]: the reference's own default also runs SURF, which is not built)."""
+    None = frame_processing.DEFAULT_FEATURES = the reference's own default ["SURF", "SIFT", "ORB"]; the north-star hot path
+    is features_type_list=["ORB"] (one fused ORB pipeline, evh_stream_homography_batch_resized)."""
     import torch
     if matching_path:
         raise NotImplementedError("matching visualisation (draw_matches + imwrite) is outside the MI355X hot path; "
@@ -46,15 +47,13 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     from .frame_processing import DEFAULT_FEATURES
     features = list(features_type_list or DEFAULT_FEATURES)
     for name in features:
-        if name == "SURF":
-            raise NotImplementedError("SURF is not built on the MI355X path; use features_type_list=['SIFT', 'ORB'] or ['ORB']")
-        if name not in ("ORB", "SIFT"):
+        if name not in ("ORB", "SIFT", "SURF"):
             raise ValueError("You need to choose descriptors type")
     multi = features != ["ORB"]
     chunk_frames = runtime.chunk_frames_for(first.nbytes, max(2, int(chunk_frames)))
     # sized for the RESIZED frames: only those go through ORB (evh_resize_area_u8 does not depend on the context's
     # geometry), so a 4K source with resize_width=400 allocates 400-wide buffers
-    ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures, sift="SIFT" in features)
+    ctx = runtime.get_context(dw, dh, chunk_frames, nfeatures, sift="SIFT" in features, surf="SURF" in features)
     dev = runtime.device()
     # Double-buffered chunk pipeline: while the GPU works on chunk i the host reads chunk i+1 from the capture into
     # pinned memory and its upload runs on a copy stream; results come back through pinned buffers.  Chunk i is
@@ -106,6 +105,8 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
                               max_frames=chunk_frames)
                 if "SIFT" in features:
                     big.sift_enable(runtime.SIFT_FEATURES)
+                if "SURF" in features:
+                    big.surf_enable(runtime.SURF_FEATURES)
             except EvhError:
                 raise EvhError("frame %d..%d: more key points (ORB ties at the retainBest cut, or SIFT key points) than "
                                "the largest frame slot this device path supports" % (frame_no[0], frame_no[0] + nb - 1))

@@ -11,14 +11,17 @@ _ctx = None
 _cfg = None
 NFEATURES = 500  # cv2.ORB_create() default used by the reference (frame_processing.py:60)
 SIFT_FEATURES = 6144  # SIFT key points reserved per frame slot (SIFT_create() keeps every key point; a textured 400x224
-                      # frame has ~2 500).  The matching filter bounds it at 7 680 - ORB's slot (evh_sift_enable).
+                      # frame has ~2 500).  The matching filter bounds a type at 7 680 key points per frame.
 
 
 def device_index():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def get_context(w, h, nframes=2, nfeatures=NFEATURES, sift=False):
+SURF_FEATURES = 4096  # SURF key points reserved per frame slot (hessianThreshold 400: ~800 on a textured 400x224 frame)
+
+
+def get_context(w, h, nframes=2, nfeatures=NFEATURES, sift=False, surf=False):
     """A context able to hold `nframes` frames of w x h with `nfeatures` keypoints each (sift=True: with the SIFT buffers,
     evh_sift_enable)."""
     global _ctx, _cfg
@@ -33,8 +36,19 @@ def get_context(w, h, nframes=2, nfeatures=NFEATURES, sift=False):
             _ctx.close()
         _ctx = _lib.Context(device=device_index(), max_w=cfg[0], max_h=cfg[1], max_features=cfg[3], max_frames=cfg[2])
         _cfg = cfg
-    if sift and _ctx.lib.evh_sift_capacity(_ctx.h) <= 0:
-        _ctx.sift_enable(SIFT_FEATURES)
+    if (sift and _ctx.lib.evh_sift_capacity(_ctx.h) <= 0) or (surf and _ctx.lib.evh_surf_capacity(_ctx.h) <= 0):
+        if getattr(_ctx, "_multi_used", False):
+            # the multi-type pair buffers are sized at their first use: a context that already ran a type list is
+            # replaced when another detector joins
+            cfg = _cfg
+            sift = sift or _ctx.lib.evh_sift_capacity(_ctx.h) > 0
+            surf = surf or _ctx.lib.evh_surf_capacity(_ctx.h) > 0
+            _ctx.close()
+            _ctx = _lib.Context(device=device_index(), max_w=cfg[0], max_h=cfg[1], max_features=cfg[3], max_frames=cfg[2])
+        if sift and _ctx.lib.evh_sift_capacity(_ctx.h) <= 0:
+            _ctx.sift_enable(SIFT_FEATURES)
+        if surf and _ctx.lib.evh_surf_capacity(_ctx.h) <= 0:
+            _ctx.surf_enable(SURF_FEATURES)
     return _ctx
 
 

@@ -15,6 +15,7 @@
  *   evh_find_homography_ransac    cv2.findHomography(a,b,cv2.RANSAC,3.0) matching.py:156-157; utils.py:356-358
  *   evh_static_filter             find_point_displacement + get_largest_group_points   utils.py:258-325
  *   evh_sift_detect_batch         cv2.xfeatures2d.SIFT_create().detectAndCompute   frame_processing.py:62-64
+ *   evh_surf_detect_batch         cv2.xfeatures2d.SURF_create(extended=1, hessianThreshold=400).detectAndCompute   frame_processing.py:65-67
  *   evh_match_knn2_l2f32          knnMatch on float32[N,128] descriptors            matching.py:102-108
  *   evh_*_homography_batch_types  concatenate_all_features_types over a type list   frame_processing.py:91-104
  *   evh_pair_homography_batch     the per-pair body of get_homography_dict video_processing.py:67-105
@@ -254,7 +255,7 @@ int evh_compute_homography(evh_ctx* ctx, const float* h_pts, int n, const double
 
 /* ---- N4: SIFT and the reference's multi-type pairs --------------------------------------------------------- */
 /* feature types of frame_processing.py:59-67; a list is processed in its own order (reference default: SURF, SIFT, ORB) */
-enum { EVH_FEATURE_ORB = 0, EVH_FEATURE_SIFT = 1, EVH_FEATURE_SURF = 2 /* not built: EVH_ERR_UNSUPPORTED */ };
+enum { EVH_FEATURE_ORB = 0, EVH_FEATURE_SIFT = 1, EVH_FEATURE_SURF = 2 };
 /* Reserves the SIFT buffers of a context: max_sift_features key points per frame slot (SIFT_create() keeps every key
  * point -- 2 500 on a textured 400x224 frame), the float scale space of a group of frames.  Call once, before the entries
  * below.  A frame that delivers more is flagged: its pairs get EVH_PAIR_CAPACITY, evh_sift_count / _download fail.    */
@@ -275,6 +276,19 @@ int evh_sift_download(evh_ctx* ctx, int frame, float* h_xy, float* h_desc, int32
  * scale space of a frame of the last detect call (octave 0 = the frame doubled)                                   */
 int evh_sift_octave_info(const evh_ctx* ctx, int octave, int* w, int* h);
 int evh_sift_download_gauss(evh_ctx* ctx, int frame, int octave, int layer, float* h_pixels /* h*w tight */);
+/* SURF: cv2.xfeatures2d.SURF_create(extended=1, hessianThreshold=400).detectAndCompute(frame, None)
+ * (frame_processing.py:65-67; OpenCV 3.4.2: 4 octaves x 3 layers, 128-float descriptors, rotation-aware).  Same call
+ * shapes as the SIFT entries; hessian_threshold = 400 for the reference.  Key points come in the operator's own order
+ * (std::sort by KeypointGreater: response descending); h_laplacian = KeyPoint::class_id (sign of the trace).        */
+int evh_surf_enable(evh_ctx* ctx, int max_surf_features);
+int evh_surf_capacity(const evh_ctx* ctx);
+int evh_surf_detect_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int src_w, int src_h, int channels,
+                          int64_t row_stride, int64_t frame_stride, int w, int h, double hessian_threshold);
+int evh_surf_count(evh_ctx* ctx, int frame);
+int evh_surf_download(evh_ctx* ctx, int frame, float* h_xy, float* h_desc /* f32[n,128] */, float* h_size, float* h_angle,
+                      float* h_response, int32_t* h_octave, int32_t* h_laplacian);
+/* test hook: the integral image (h+1) x (w+1) of a frame of the last SURF call                                      */
+int evh_surf_download_integral(evh_ctx* ctx, int frame, int32_t* h_sum);
 /* DescriptorMatcher("BruteForce").knnMatch(q, t, 2) on FLOAT descriptors (matching.py:102-108 with the float32[N,128]
  * rows of SIFT / SURF; dim = 64 or 128): d_idx i32[nq,2] (-1 = missing neighbour), d_dist f32[nq,2] (L2 distances,
  * summed in the operator's order).  Ties -> lowest train index.                                                      */
@@ -288,7 +302,8 @@ int evh_ratio_unique_filter_f32(evh_ctx* ctx, const int32_t* d_idx, const float*
  * FrameProcessing(frame, features_type_list).concatenate_all_features_types (frame_processing.py:91-104): per type
  * detect + match + RANSAC #1 + static filter, the static rows of all types concatenated, remove_double_matching again,
  * then compute_homography.  A type that fails (NoMatchesException) fails the pair with its status.  (src_w, src_h) /
- * (w, h) as in evh_stream_homography_batch_resized.  Needs evh_sift_enable when the list holds SIFT.  Do not synchronise. */
+ * (w, h) as in evh_stream_homography_batch_resized.  Needs evh_sift_enable / evh_surf_enable (BEFORE the first such call)
+ * when the list holds SIFT / SURF.  Do not synchronise.                                                                */
 int evh_pair_homography_batch_types(evh_ctx* ctx, const uint8_t* d_frames, int npairs, int mode, int src_w, int src_h,
                                     int channels, int64_t row_stride, int64_t frame_stride, int w, int h, int nfeatures,
                                     const int32_t* h_types, int ntypes, double ransac_thr, int ransac_max_iters,

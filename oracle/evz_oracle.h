@@ -71,7 +71,12 @@ void evo_knn2_l2f32(const float* q, int nq, const float* t, int nt, int dim, int
 int evo_ratio_unique_f32(const int32_t* idx, const float* dist, int nq, double ratio, int32_t* out_q, int32_t* out_t);
 int evo_match_static_f32(const float* xy_a, const float* desc_a, int na, const float* xy_b, const float* desc_b, int nb,
                          int dim, float* oa, float* ob, int* out_n);
-/* one stream with a LIST of feature types (0 = ORB, 1 = SIFT), frame_processing.py:91-104 + video_processing.py:67-105 */
+/* ---- N4: SURF (frame_processing.py:65-67 SURF_create(extended=1, hessianThreshold=400).detectAndCompute), evz_surf.cpp ---- */
+/* RESTATED FROM RECALL, PARITY UNPINNED (see the header of evz_surf.cpp) */
+void evo_integral(const uint8_t* gray, int w, int h, int32_t* sum);
+int evo_surf_detect(const uint8_t* gray, int w, int h, float* xy, float* desc, float* size, float* angle, float* response,
+                    int* octave, int* laplacian, int cap);
+/* one stream with a LIST of feature types (0 = ORB, 1 = SIFT, 2 = SURF), frame_processing.py:91-104 + video_processing.py:67-105 */
 int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types, int ntypes,
                           double* H, int* status);
 

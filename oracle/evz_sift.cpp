@@ -602,6 +602,11 @@ void detect_type(const uint8_t* gray, int w, int h, int nfeatures, int type, TFe
     if (f.n > cap) f.n = cap;
     f.df.resize((size_t)128 * f.n);
     for (size_t i = 0; i < f.df.size(); i++) f.df[i] = (float)f.d8[i];
+  } else if (type == 2) {                                    /* SURF */
+    int cap = 65536;
+    f.xy.resize(2 * (size_t)cap); f.df.resize((size_t)128 * cap);
+    f.n = evo_surf_detect(gray, w, h, f.xy.data(), f.df.data(), nullptr, nullptr, nullptr, nullptr, nullptr, cap);
+    if (f.n > cap) f.n = cap;
   } else {                                                   /* ORB */
     int cap = nfeatures * 2 + 4096;
     f.xy.resize(2 * (size_t)cap); f.d8.resize((size_t)32 * cap);
@@ -611,7 +616,7 @@ void detect_type(const uint8_t* gray, int w, int h, int nfeatures, int type, TFe
 }
 }  // namespace
 
-/* one stream, a list of feature types (0 = ORB, 1 = SIFT) processed in list order; H [F-1][9], status [F-1]; returns the
+/* one stream, a list of feature types (0 = ORB, 1 = SIFT, 2 = SURF) processed in list order; H [F-1][9], status [F-1]; returns the
  * index of a failing FIRST pair or -1 (as evo_stream_gray) */
 extern "C" int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types,
                                      int ntypes, double* H, int* status) {
@@ -629,7 +634,7 @@ extern "C" int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, 
       const TFeat& a = cur[t]; const TFeat& b = prev[t];
       std::vector<float> oa(2 * (size_t)std::max(a.n, 1)), ob(2 * (size_t)std::max(a.n, 1));
       int n = 0;
-      if (types[t] == 1) st = evo_match_static_f32(a.xy.data(), a.df.data(), a.n, b.xy.data(), b.df.data(), b.n, 128, oa.data(), ob.data(), &n);
+      if (types[t] != 0) st = evo_match_static_f32(a.xy.data(), a.df.data(), a.n, b.xy.data(), b.df.data(), b.n, 128, oa.data(), ob.data(), &n);
       else st = evo_match_static(a.xy.data(), a.d8.data(), a.n, b.xy.data(), b.d8.data(), b.n, oa.data(), ob.data(), &n);
       if (st == EVO_OK) { alla.insert(alla.end(), oa.begin(), oa.begin() + 2 * n); allb.insert(allb.end(), ob.begin(), ob.begin() + 2 * n); }
     }

@@ -339,7 +339,7 @@ def match_static_f32(xy_a, desc_a, xy_b, desc_b):
     return st, oa[:n.value].copy(), ob[:n.value].copy()
 
 
-FEATURE_CODES = {"ORB": 0, "SIFT": 1}
+FEATURE_CODES = {"ORB": 0, "SIFT": 1, "SURF": 2}
 
 
 def stream_gray_types(frames, features, nfeatures=500):
@@ -350,3 +350,25 @@ def stream_gray_types(frames, features, nfeatures=500):
     H = np.zeros((nf - 1, 9), np.float64); st = np.zeros(nf - 1, np.int32)
     rc = lib().evo_stream_gray_types(_p(frames), nf, w, h, nfeatures, _p(t), len(t), _p(H), _p(st))
     return H.reshape(-1, 3, 3), st, rc
+
+
+# ---- N4: SURF (oracle/evz_surf.cpp; restated from recall, parity unpinned) -------------------------------------------
+def integral(gray):
+    gray = _u8(gray)
+    h, w = gray.shape
+    out = np.zeros((h + 1, w + 1), np.int32)
+    lib().evo_integral(_p(gray), w, h, _p(out))
+    return out
+
+
+def surf_detect(gray, cap=65536):
+    """SURF_create(extended=1, hessianThreshold=400).detectAndCompute -> dict(xy, desc f32[N,128], size, angle, response,
+    octave, laplacian) in the operator's own order (response descending)."""
+    gray = _u8(gray)
+    h, w = gray.shape
+    xy = np.zeros((cap, 2), np.float32); desc = np.zeros((cap, 128), np.float32); sz = np.zeros(cap, np.float32)
+    an = np.zeros(cap, np.float32); rs = np.zeros(cap, np.float32); oc = np.zeros(cap, np.int32); lp = np.zeros(cap, np.int32)
+    n = lib().evo_surf_detect(_p(gray), w, h, _p(xy), _p(desc), _p(sz), _p(an), _p(rs), _p(oc), _p(lp), cap)
+    assert n <= cap, "raise cap"
+    return dict(xy=xy[:n].copy(), desc=desc[:n].copy(), size=sz[:n].copy(), angle=an[:n].copy(), response=rs[:n].copy(),
+                octave=oc[:n].copy(), laplacian=lp[:n].copy())

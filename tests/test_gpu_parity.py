@@ -197,7 +197,8 @@ def test_frame_capacity_is_a_pair_status(ctx):
         ctx.orb_download(2)
     assert len(ctx.orb_download(1)["xy"]) == len(O.orb_detect(cur)["xy"])
     # the Python stream driver re-runs such a chunk on larger frame slots (test_tie_heavy_frame_mid_stream_...)
-    d = get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in (prev, cur, crowded, cur)]), resize_width=400)
+    d = get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in (prev, cur, crowded, cur)]), resize_width=400,
+                            features_type_list=["ORB"])
     Hs, ss, _ = O.stream_gray(np.stack([prev, cur, crowded, cur]))
     assert np.allclose(np.array([d[k]["H"] for k in (2, 3, 4)]), Hs, rtol=1e-9, atol=1e-12)
 
@@ -722,14 +723,12 @@ def test_python_api_mirror_vs_oracle():
     frames, _ = S.make_stream(9, 6, 400, 224)
     bgr = S.gray_to_bgr(frames)
     # per-call API (frame_processing.py / matching.py / utils.py signatures)
-    fa, fb = FrameProcessing(bgr[1]), FrameProcessing(bgr[0])
+    fa, fb = FrameProcessing(bgr[1], ["ORB"]), FrameProcessing(bgr[0], ["ORB"])
     xy, desc = fa.detect_and_describe_features("ORB")
     o = O.orb_detect(frames[1])
     assert xy.dtype == np.float32 and desc.dtype == np.uint8 and np.array_equal(xy, o["xy"]) and np.array_equal(desc, o["desc"])
     with pytest.raises(ValueError):
         fa.detect_and_describe_features("BRISK")
-    with pytest.raises(NotImplementedError):
-        fa.detect_and_describe_features("SURF")
     pa, pb = fa.concatenate_all_features_types(fb)
     ob = O.orb_detect(frames[0])
     st, sa, sb = O.match_static(o["xy"], o["desc"], ob["xy"], ob["desc"])
@@ -750,12 +749,12 @@ def test_python_api_mirror_vs_oracle():
     Hs, sts, rc = O.stream_gray(frames)
     assert rc == -1
     for chunk in (64, 3):
-        d = get_homography_dict(S.SyntheticCapture(list(bgr)), resize_width=400, chunk_frames=chunk)
+        d = get_homography_dict(S.SyntheticCapture(list(bgr)), resize_width=400, chunk_frames=chunk, features_type_list=["ORB"])
         assert list(d.keys()) == [2, 3, 4, 5, 6, "resize_info"] and d["resize_info"] == {"h": 224, "w": 400}
         for k in range(2, 7):
             assert np.allclose(np.array(d[k]["H"]), Hs[k - 2], rtol=1e-9, atol=1e-12)
     # resize_width smaller than the frame: INTER_AREA on the GPU, then the same path
-    d = get_homography_dict(S.SyntheticCapture(list(bgr)), resize_width=320)
+    d = get_homography_dict(S.SyntheticCapture(list(bgr)), resize_width=320, features_type_list=["ORB"])
     small = np.stack([O.bgr2gray(O.resize_area(f, 320, 179)) for f in bgr])
     Hs2, st2, rc2 = O.stream_gray(small)
     assert d["resize_info"] == {"h": 179, "w": 320} and rc2 == -1
@@ -1056,7 +1055,8 @@ def test_long_pan_stream_600_frames_chunked():
     Ho, so, rc = O.stream_gray(frames)
     assert rc == -1 and list(so[300:303]) == [1, 1, 1] and (so == 0).sum() >= n - 1 - 3 - 5
     # (1) the Python stream driver, chunked + double-buffered
-    d = get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in frames]), resize_width=w, chunk_frames=17)
+    d = get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in frames]), resize_width=w, chunk_frames=17,
+                            features_type_list=["ORB"])
     assert d["resize_info"] == {"h": h, "w": w} and sorted(k for k in d if k != "resize_info") == list(range(2, n + 1))
     Hd = np.array([d[k]["H"] for k in range(2, n + 1)])
     assert np.allclose(Hd, Ho, rtol=1e-9, atol=1e-12)
@@ -1101,6 +1101,7 @@ def test_tie_heavy_frame_mid_stream_reruns_on_larger_slots():
     Ho, so, rc = O.stream_gray(frames)
     assert rc == -1
     for chunk in (4, 64):
-        d = get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in frames]), resize_width=w, chunk_frames=chunk)
+        d = get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in frames]), resize_width=w, chunk_frames=chunk,
+                                features_type_list=["ORB"])
         Hd = np.array([d[k]["H"] for k in range(2, len(frames) + 1)])
         assert np.allclose(Hd, Ho, rtol=1e-9, atol=1e-12), chunk

@@ -202,8 +202,6 @@ def test_python_mirror_sift_and_type_list():
     o1, o0 = O.sift_detect(frames[1]), O.sift_detect(frames[0])
     assert xy.dtype == np.float32 and desc.dtype == np.float32 and desc.shape[1] == 128
     assert np.array_equal(xy, o1["xy"]) and np.array_equal(desc, o1["desc"])
-    with pytest.raises(NotImplementedError):
-        fa.detect_and_describe_features("SURF")
     # KeyPoints on float descriptors: match_kps / match_static_kps
     pa, pb = KeyPoints(o1["xy"], o1["desc"]).match_kps(KeyPoints(o0["xy"], o0["desc"]))
     oi, od = O.knn2_f32(o1["desc"], o0["desc"])
@@ -223,4 +221,111 @@ def test_python_mirror_sift_and_type_list():
     d = get_homography_dict(S.SyntheticCapture(bgr), resize_width=w, chunk_frames=3, features_type_list=["SIFT", "ORB"])
     got = np.array([d[k]["H"] for k in range(2, len(frames) + 1)])
     assert rc == -1 and (ss == 0).all() and np.allclose(got, Hs, rtol=1e-9, atol=1e-12)
+    runtime.reset()
+
+
+# ---- SURF (frame_processing.py:65-67) ---------------------------------------------------------------------------------
+def make_surf_ctx(w, h, frames=4, surf=4096, sift=0):
+    from evenvizion_amd._lib import Context
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=frames)
+    c.surf_enable(surf)
+    if sift:
+        c.sift_enable(sift)
+    return c
+
+
+def _same_surf(g, o):
+    assert len(g["xy"]) == len(o["xy"]), (len(g["xy"]), len(o["xy"]))
+    for k in ("xy", "size", "angle", "response", "desc"):
+        assert np.array_equal(g[k].view(np.uint32), o[k].view(np.uint32)), k
+    assert np.array_equal(g["octave"], o["octave"]) and np.array_equal(g["laplacian"], o["laplacian"])
+
+
+@pytest.mark.parametrize("w,h,cap", [(400, 224, 4096), (333, 217, 4096), (1280, 720, 16384), (97, 131, 1024)])
+def test_surf_keypoints_and_descriptors(w, h, cap):
+    """SURF_create(extended=1, hessianThreshold=400).detectAndCompute: the integral image, the key points in the operator's
+    order (x, y, size, angle, response, octave, laplacian) and the 128-float descriptors, all BIT FOR BIT."""
+    prev, cur, _ = S.make_pair(41, w, h)
+    c = make_surf_ctx(w, h, frames=2, surf=cap)
+    try:
+        c.surf_detect_batch(dev(np.stack([prev, cur])))
+        for f, img in enumerate((prev, cur)):
+            assert np.array_equal(c.surf_download_integral(f), O.integral(img))
+            _same_surf(c.surf_download(f), O.surf_detect(img))
+        c.surf_detect_batch(dev(np.stack([S.gray_to_bgr(prev), S.gray_to_bgr(cur)])))
+        _same_surf(c.surf_download(1), O.surf_detect(cur))
+        flat = np.full((2, h, w), 77, np.uint8)
+        c.surf_detect_batch(dev(flat))
+        assert len(c.surf_download(0)["xy"]) == 0 and len(O.surf_detect(flat[0])["xy"]) == 0
+    finally:
+        c.close()
+
+
+def test_surf_large_scales_and_image_borders():
+    """Big blobs: key points of the upper octaves (window sides of several hundred pixels, sampled past the image border,
+    the integer-ratio INTER_AREA path among them) and key points whose orientation samples partly fall outside."""
+    w, h = 640, 480
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.full((h, w), 128.0)
+    rng = np.random.default_rng(3)
+    for k in range(160):
+        cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(3, 45)
+        a = rng.uniform(30, 90) * (1 if k % 2 else -1)
+        img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r))
+    img = np.clip(img + rng.normal(0, 1.5, img.shape), 0, 255).astype(np.uint8)
+    o = O.surf_detect(img)
+    assert (o["octave"] >= 2).sum() >= 30 and o["size"].max() > 200          # 67 key points, window sides up to 632
+    c = make_surf_ctx(w, h, frames=2)
+    try:
+        c.surf_detect_batch(dev(np.stack([img, img[::-1].copy()])))
+        _same_surf(c.surf_download(0), o)
+        _same_surf(c.surf_download(1), O.surf_detect(img[::-1].copy()))
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("features", [["SURF"], ["SURF", "SIFT", "ORB"]])
+def test_reference_default_type_list_stream_vs_oracle(features):
+    """The reference's default FrameProcessing list (frame_processing.py:40) end to end in stream semantics."""
+    w, h = 400, 224
+    frames, _ = S.make_stream(43, 5, w, h)
+    flat = np.full((h, w), 128, np.uint8)
+    frames = np.stack([frames[0], frames[1], flat, frames[2], frames[3], frames[4]])
+    n = len(frames) - 1
+    Ho, so, rc = O.stream_gray_types(frames, features)
+    assert rc == -1 and list(so) == [0, 1, 1, 0, 0]
+    c = make_surf_ctx(w, h, frames=len(frames), surf=4096, sift=4096)
+    try:
+        H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch_types(dev(frames), H, st, features)
+        c.synchronize()
+        assert np.array_equal(st.cpu().numpy(), so)
+        assert np.allclose(H.cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
+    finally:
+        c.close()
+
+
+def test_python_mirror_default_is_the_reference_default():
+    """get_homography_dict(capture) / FrameProcessing(frame) with NO feature list = SURF + SIFT + ORB, like the reference
+    (video_processing.py:69,74 -> frame_processing.py:40)."""
+    from evenvizion_amd import runtime
+    from evenvizion_amd.processing import FrameProcessing, get_homography_dict
+    runtime.reset()
+    w, h = 400, 224
+    frames, _ = S.make_stream(47, 4, w, h)
+    bgr = [S.gray_to_bgr(f) for f in frames]
+    fa = FrameProcessing(bgr[1])
+    assert fa.features_types == ["SURF", "SIFT", "ORB"]
+    xy, desc = fa.detect_and_describe_features("SURF")
+    o = O.surf_detect(frames[1])
+    assert desc.dtype == np.float32 and np.array_equal(xy, o["xy"]) and np.array_equal(desc, o["desc"])
+    Hs, ss, rc = O.stream_gray_types(frames, ["SURF", "SIFT", "ORB"])
+    d = get_homography_dict(S.SyntheticCapture(bgr), resize_width=w, chunk_frames=3)
+    got = np.array([d[k]["H"] for k in range(2, len(frames) + 1)])
+    assert rc == -1 and (ss == 0).all() and np.allclose(got, Hs, rtol=1e-9, atol=1e-12)
+    # per-pair body through the class API
+    ca, cb = fa.concatenate_all_features_types(FrameProcessing(bgr[0]))
+    from evenvizion_amd.processing import compute_homography
+    assert np.allclose(compute_homography(ca, cb, None), Hs[0], rtol=1e-9, atol=1e-12)
     runtime.reset()

@@ -154,7 +154,8 @@ def test_driver_loop_matches_reference(goldens, monkeypatch, chunk):
     for c in goldens["driver_loop"]["cases"]:
         fake = _FakeCtx(c["plan"])
         monkeypatch.setattr(runtime, "get_context", lambda *a, **k: fake)
-        res = video_processing.get_homography_dict(_Cap(c["nframes"]), resize_width=c["resize_width"], chunk_frames=chunk)
+        res = video_processing.get_homography_dict(_Cap(c["nframes"]), resize_width=c["resize_width"], chunk_frames=chunk,
+                                                   features_type_list=["ORB"])
         want = c["result"]
         assert [str(k) for k in res.keys()] == list(want.keys())          # 2..n then "resize_info" last
         assert res["resize_info"] == want["resize_info"]
@@ -169,19 +170,22 @@ def test_driver_loop_matches_reference(goldens, monkeypatch, chunk):
     fake = _FakeCtx({"1": "nomatch", "2": np.eye(3).tolist()})
     monkeypatch.setattr(runtime, "get_context", lambda *a, **k: fake)
     with pytest.raises(AttributeError):
-        video_processing.get_homography_dict(_Cap(3), resize_width=8, chunk_frames=chunk)
+        video_processing.get_homography_dict(_Cap(3), resize_width=8, chunk_frames=chunk, features_type_list=["ORB"])
     with pytest.raises(ValueError):
         video_processing.get_homography_dict(_Cap(0))
     with pytest.raises(NotImplementedError):
         video_processing.get_homography_dict(_Cap(3), matching_path="/tmp/x")
-    with pytest.raises(NotImplementedError):
-        video_processing.get_homography_dict(_Cap(3), features_type_list=["SURF", "SIFT", "ORB"])
     with pytest.raises(ValueError):
         video_processing.get_homography_dict(_Cap(3), features_type_list=["BRISK"])
     fake = _FakeCtx({"1": np.eye(3).tolist(), "2": np.eye(3).tolist()})
     monkeypatch.setattr(runtime, "get_context", lambda *a, **k: fake)
     res = video_processing.get_homography_dict(_Cap(3), resize_width=8, chunk_frames=chunk, features_type_list=["SIFT", "ORB"])
     assert fake.types_calls >= 1 and sorted(k for k in res if k != "resize_info") == [2, 3]
+    before = fake.types_calls
+    video_processing.get_homography_dict(_Cap(3), resize_width=8, chunk_frames=chunk)      # default list = the reference's three
+    assert fake.types_calls > before
+    from evenvizion_amd.processing import frame_processing
+    assert frame_processing.DEFAULT_FEATURES == ["SURF", "SIFT", "ORB"]                      # frame_processing.py:40
 
 
 def test_install_as_evenvizion_keeps_the_real_package_reachable(tmp_path, monkeypatch):

@@ -14,9 +14,9 @@ for case in cases:
     idx = [i % 32 if i % 32 <= 16 else 32 - i % 32 for i in range(nfr)]
     frames = [S.gray_to_bgr(gray[i][None])[0] for i in range(17)]
     seq = [frames[i] for i in idx]
-    get_homography_dict(S.SyntheticCapture(seq[:66]), resize_width=rw)          # warm-up (context, first import)
+    get_homography_dict(S.SyntheticCapture(seq[:66]), resize_width=rw, features_type_list=["ORB"])          # warm-up (context, first import)
     t = time.perf_counter()
-    d = get_homography_dict(S.SyntheticCapture(seq), resize_width=rw)
+    d = get_homography_dict(S.SyntheticCapture(seq), resize_width=rw, features_type_list=["ORB"])
     dt = time.perf_counter() - t
     res[case] = dict(pairs=len(d) - 1, seconds=round(dt, 3), pairs_per_s=round((len(d) - 1) / dt, 1))
 print(json.dumps(res, indent=1))
