@@ -373,8 +373,17 @@ def main():
         if entry is None:
             continue
         if field == "traffic":
-            roofline["traffic"] = entry
-            roofline["traffic_source"] = "replayed: profiles/%s[%s] (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % (fname, key)
+            if isinstance(entry, dict):
+                roofline["traffic"] = entry["hbm_bytes"]
+                roofline["traffic_correction"] = {
+                    "fetch_factor": entry["fetch_correction"], "fetch_counter_bytes": entry["fetch_counter_bytes"],
+                    "write_bytes": entry["write_bytes"],
+                    "why": "FETCH_SIZE tallies 128-byte lines at 64 bytes on gfx950; calibrated on this kernel's own staging "
+                           "pattern: profiles/r03_fetch_calibration.txt"}
+            else:                     # a round-2 record: raw counter sum
+                roofline["traffic"] = entry
+            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / max(by, 1), 3)
+            roofline["traffic_source"] = "replayed: profiles/%s[%s] (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)" % (fname, key)
         elif stage_ms[dom] > 0:
             props = torch.cuda.get_device_properties(dev)
             per = entry["valu_wave_insts_per_launch"] / (stage_ms[dom] * 1e-3) / (props.multi_processor_count * 2.4e9)
@@ -391,6 +400,29 @@ def main():
     pipe_bytes = (2 if args.kind == "pairs" else 1) * sum(per_frame.values()) + sum(per_pair.values())
     roofline["pipeline_bytes_per_pair"] = int(pipe_bytes)
     roofline["pipeline_frac"] = round(pipe_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)
+    # the same with SURVEY 8d's own byte model: B_frame = A*(1 + (P-1) + P) + min(P*A, 1369*N) + 48*N with the gray frame
+    # resident (+ 3*A when the BGR entry is timed), B_match = 72*N, B_out = 80 -- source read once, levels 1..7 written
+    # once, every level read once; no re-read by the unfused pyramid, no write of level 0
+    A8 = areas_sum = None
+    lv8 = level_sizes(w, h)
+    A8 = lv8[0][0] * lv8[0][1]; areas_sum = sum(a * b for a, b in lv8)
+    b_frame = A8 + (areas_sum - A8) + areas_sum + min(areas_sum, 1369 * nfeat) + 48 * nfeat + (3 * A8 if args.channels == 3 else 0)
+    pipe8d = (2 if args.kind == "pairs" else 1) * b_frame + 72 * nfeat + 80
+    roofline["pipeline_bytes_per_pair_survey8d"] = int(pipe8d)
+    roofline["pipeline_frac_survey8d"] = round(pipe8d * value / world / 1e9 / HBM_PEAK_GBS, 5)
+
+    # rocprof-measured HBM bytes of a whole step (corrected FETCH_SIZE + WRITE_SIZE over every kernel, committed PMC passes of
+    # this workload) against this run's step time: what "rocprof HBM GB/s against the chip's peak" reads for the path
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        ent = tj.get("step@%dx%dx%d_n%d_c%d" % (w, h, B, nfeat, args.channels)) if args.kind == "pairs" else None
+    except Exception:
+        ent = None
+    if ent:
+        gbs = ent["hbm_bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
+        roofline["hbm_traffic"] = {"bytes_per_step": ent["hbm_bytes_per_step"], "GBps": round(gbs, 1),
+                                   "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                   "source": "replayed: " + ent["source"] + "; step time of this run"}
 
     # ---- CPU baseline (oracle) on a bounded sample, rank 0 at N=1 only --------------------------------------------------
     cpu_baseline = None

@@ -6,10 +6,13 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --gen-procs 1 --unique 16 --skip-no-temporal > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 16 --skip-no-temporal > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 16 --skip-no-temporal > $O/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS -d $O/sq -o sq --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 16 --skip-no-temporal > $O/sq.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --gen-procs 1 --unique 64 --skip-no-temporal > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS -d $O/sq -o sq --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/sq.log 2>&1
+# exact read requests by size (cross-check of the FETCH_SIZE correction: bytes = 32*n32 + 64*n64 + 128*n128); may be refused
+# when the three do not fit one pass -- then the calibrated factor of profiles/r03_fetch_calibration.txt stands alone
+(rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/rdreq -o rdreq --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/rdreq.log 2>&1 || true)
 # the stream workload (BASELINE configs[2]): kernel stats only
 rocprofv3 --kernel-trace --stats -d $O/stats3 -o stats3 --output-format csv -- python3 $R/bench.py --config 3 --steps 4 --warmup 1 --cpu-pairs 0 > $O/stats3.log 2>&1
 cd $R && python bench.py > $O/bench.json 2> $O/bench.err

@@ -7,9 +7,12 @@
   profiles/<tag>_bench_n1.json        the bench line of the same box
   profiles/traffic.json               HBM bytes per launch of the dominant kernel group (read by bench.py)
 
-FETCH_SIZE / WRITE_SIZE units: the counters are in 1 KiB units on gfx950 as collected here (x1024 -> bytes); see
-/opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section) for the wide-stream under-count noted in the CSV.
+FETCH_SIZE / WRITE_SIZE units: KiB (x1024 -> bytes).  FETCH_SIZE tallies every 128-byte line at 64 bytes on gfx950
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section); calibrated on k_fast_main's own staging pattern
+(profiles/r03_fetch_calibration.txt): the factor is exactly 2 for every request shape this path uses, so the HBM read
+bytes written below are 2 x FETCH_SIZE x 1024.  WRITE_SIZE is exact for 16-byte-per-lane stores.
 """
+FETCH_CORRECTION = 2.0
 import csv, collections, glob, json, os, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -56,28 +59,45 @@ def per_kernel(sub, counter):
 
 fetch = per_kernel("fetch", "FETCH_SIZE")
 write = per_kernel("write", "WRITE_SIZE")
+rd32 = per_kernel("rdreq", "TCC_EA0_RDREQ_32B_sum")
+rd64 = per_kernel("rdreq", "TCC_EA0_RDREQ_64B_sum")
+rd128 = per_kernel("rdreq", "TCC_EA0_RDREQ_128B_sum")
 rows = []
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):
         continue
     fb = 1024.0 * sum(fetch.get(k, [0])) / max(len(fetch.get(k, [1])), 1)
     wb = 1024.0 * sum(write.get(k, [0])) / max(len(write.get(k, [1])), 1)
-    rows.append((k, len(fetch.get(k, [])), fb, wb))
+    n_rd = max(len(rd128.get(k, [])), 1)
+    exact = (32.0 * sum(rd32.get(k, [])) + 64.0 * sum(rd64.get(k, [])) + 128.0 * sum(rd128.get(k, []))) / n_rd if k in rd128 else float("nan")
+    rows.append((k, len(fetch.get(k, [])), fb, wb, exact))
 with open(os.path.join(out, tag + "_pmc_hbm_traffic.csv"), "w") as fo:
     fo.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes): python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0\n")
     fo.write("# workload: 1024 independent 1280x720 BGR pairs per launch (2048 frames), ORB 500; average bytes per kernel launch = counter x 1024\n")
-    fo.write("# FETCH_SIZE reads ~1:1 for 8-byte-per-lane tile staging (k_fast_*) and about one half of wide coalesced streams (guide, HBM section)\n")
-    fo.write("kernel,launches,fetch_bytes_per_launch,write_bytes_per_launch\n")
-    for k, n, fb, wb in rows:
-        fo.write("%s,%d,%.0f,%.0f\n" % (k, n, fb, wb))
+    fo.write("# fetch_counter_bytes = FETCH_SIZE x 1024 as reported; hbm_read_bytes = %.1f x that (128-byte lines tallied at 64 bytes: profiles/r03_fetch_calibration.txt)\n" % FETCH_CORRECTION)
+    fo.write("# rdreq_bytes = 32*TCC_EA0_RDREQ_32B + 64*_64B + 128*_128B of a separate pass (nan = pass not collected): the direct count of the same reads\n")
+    fo.write("kernel,launches,fetch_counter_bytes_per_launch,hbm_read_bytes_per_launch,write_bytes_per_launch,rdreq_bytes_per_launch\n")
+    for k, n, fb, wb, ex in rows:
+        fo.write("%s,%d,%.0f,%.0f,%.0f,%.0f\n" % (k, n, fb, FETCH_CORRECTION * fb, wb, ex))
 
 # traffic.json: dominant group = FAST (sample + main [+ redo]) per step
 steps = max(len(fetch.get("k_fast_main", [])), 1)
-fast_bytes = 0.0
-for k in ("k_fast_sample", "k_fast_main", "k_fast_redo", "k_fast_thr", "k_fast_verify", "k_fast"):
-    fast_bytes += 1024.0 * (sum(fetch.get(k, [])) + sum(write.get(k, []))) / steps
-if fast_bytes > 0:
-    json.dump({"fast@1280x720x1024_n500_c3": int(fast_bytes)}, open(os.path.join(out, "traffic.json"), "w"))
+fast_fetch = fast_write = 0.0
+for k in ("k_fast_sample", "k_fast_main", "k_fast_redo", "k_fast_thr", "k_fast_verify", "k_fast", "k_fast_hint"):
+    fast_fetch += 1024.0 * sum(fetch.get(k, [])) / steps
+    fast_write += 1024.0 * sum(write.get(k, [])) / steps
+# every kernel of a step: the rocprof-measured HBM bytes the whole path moves per step (corrected reads + writes)
+step_total = 0.0
+for k in set(fetch) | set(write):
+    if k.startswith("k_"):
+        step_total += (FETCH_CORRECTION * 1024.0 * sum(fetch.get(k, [])) + 1024.0 * sum(write.get(k, []))) / steps
+if fast_fetch > 0:
+    json.dump({"step@1280x720x1024_n500_c3": {"hbm_bytes_per_step": int(step_total), "source": "profiles/%s_pmc_hbm_traffic.csv (all k_* kernels of a step)" % tag},
+               "fast@1280x720x1024_n500_c3": {"fetch_counter_bytes": int(fast_fetch), "write_bytes": int(fast_write),
+                                              "fetch_correction": FETCH_CORRECTION,
+                                              "hbm_bytes": int(FETCH_CORRECTION * fast_fetch + fast_write),
+                                              "source": "profiles/%s_pmc_hbm_traffic.csv" % tag}},
+              open(os.path.join(out, "traffic.json"), "w"))
 
 # 3. SQ breakdown
 f = find("sq", "*counter_collection.csv")
@@ -121,7 +141,7 @@ if os.path.exists(b):
         rf = d["roofline"]
         tj = json.load(open(os.path.join(out, "traffic.json")))
         if rf.get("kernel") == "fast" and key in tj:
-            rf["traffic"] = tj[key]
+            rf["traffic"] = tj[key]["hbm_bytes"]
         vj = json.load(open(os.path.join(out, "valu.json"))).get(key)
         if vj and "valu_issue" in rf and rf.get("avg_launch_ms"):
             rf["valu_issue"]["wave_insts_per_launch"] = vj["valu_wave_insts_per_launch"]
