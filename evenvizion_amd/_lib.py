@@ -52,6 +52,7 @@ SIGNATURES = {
     "evh_orb_download_level": (_i, [_vp, _i, _i, _vp]),
     "evh_orb_download_candidates": (_i, [_vp, _i, _i, _vp, _i]),
     "evh_match_knn2_l2u8": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "evh_match_knn2_l2u8x128": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "evh_match_knn2_hamming": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "evh_ratio_unique_filter": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _i, _vp, _pi, _pi]),
     "evh_find_homography_ransac": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _vp, _pi, _vp]),
@@ -293,7 +294,8 @@ class Context:
     # ---- K7 + glue ----
     def knn2(self, q, t, idx, d2, hamming=False):
         self._enter()
-        f = self.lib.evh_match_knn2_hamming if hamming else self.lib.evh_match_knn2_l2u8
+        f = self.lib.evh_match_knn2_hamming if hamming else (
+            self.lib.evh_match_knn2_l2u8x128 if q.shape[1] == 128 else self.lib.evh_match_knn2_l2u8)
         self._check(f(self.h, q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0], idx.data_ptr(), d2.data_ptr()))
 
     def ratio_unique_filter(self, idx, d2, xy_q, xy_t, pts, ratio=0.5, min_matches=4):

@@ -745,18 +745,21 @@ int evh_orb_download_candidates(evh_ctx* c, int frame, int level, uint32_t* h_pa
 }
 
 static int knn_generic(evh_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, uint32_t* d_d2,
-                       int hamming) {
+                       int hamming, int desc_bytes = 32) {
   if (!c || !d_idx || !d_d2 || nq < 0 || nt < 0) return evh_fail(c, EVH_ERR_INVALID, "evh_match_knn2: bad argument");
   if (nq == 0) return EVH_SUCCESS;
   if (((uintptr_t)d_q | (uintptr_t)d_t) & 15) return evh_fail(c, EVH_ERR_INVALID, "descriptor buffers must be 16-byte aligned");
   EvhKnnArgs K{};
   K.q = d_q; K.t = d_t; K.slot_bytes = 0; K.nq_fixed = nq; K.nt_fixed = nt;
-  K.idx = d_idx; K.d2 = d_d2; K.out_stride = nq; K.hamming = hamming;
+  K.idx = d_idx; K.d2 = d_d2; K.out_stride = nq; K.hamming = hamming; K.desc_bytes = desc_bytes;
   return evh_launch_knn2(c, K, 1);
 }
 
 int evh_match_knn2_l2u8(evh_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, uint32_t* d_d2) {
   return knn_generic(c, d_q, nq, d_t, nt, d_idx, d_d2, 0);
+}
+int evh_match_knn2_l2u8x128(evh_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx, uint32_t* d_d2) {
+  return knn_generic(c, d_q, nq, d_t, nt, d_idx, d_d2, 0, 128);
 }
 int evh_match_knn2_hamming(evh_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
                            uint32_t* d_d2) {

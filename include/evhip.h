@@ -166,6 +166,11 @@ int evh_orb_download_candidates(evh_ctx* ctx, int frame, int level, uint32_t* h_
 /* d_idx i32[nq,2] (-1 = missing neighbour), d_d2 u32[nq,2].  Ties -> lowest train index.                      */
 int evh_match_knn2_l2u8(evh_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
                         uint32_t* d_d2);
+/* the same on 128-byte rows: SIFT's descriptor values (0..255 each, held by the operator as float32; its float sums of
+ * squared differences are exact integers).  Squared distances up to 8 323 200: neighbours are compared AFTER sqrt in
+ * float32 like the operator does (two different D above 2^22 can round to the same distance and then tie).          */
+int evh_match_knn2_l2u8x128(evh_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
+                            uint32_t* d_d2);
 int evh_match_knn2_hamming(evh_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
                            uint32_t* d_d2);
 /* ratio test (d0 < d1*ratio on f32 sqrt distances, evaluated in f64), one-to-one filter, duplicate-coordinate

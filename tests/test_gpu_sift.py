@@ -329,3 +329,36 @@ def test_python_mirror_default_is_the_reference_default():
     from evenvizion_amd.processing import compute_homography
     assert np.allclose(compute_homography(ca, cb, None), Hs[0], rtol=1e-9, atol=1e-12)
     runtime.reset()
+
+
+def test_byte_matcher_on_128_byte_rows_ties_after_sqrt():
+    """evh_match_knn2_l2u8x128 (the fused path's SIFT matcher): exact integer squared distances, but neighbours are ranked
+    like the operator ranks them -- by sqrt in float32, where two different D above 2^22 can collide and then the LOWER
+    train index wins.  112 saturated, complementary dimensions put D near 7e6; 16 neutral dimensions carry 0..4 unit bumps
+    per train row, so D0, D0+1, ... D0+4 compete: in about a third of the queries the float ranking differs from the
+    integer one.  The float matcher on the same values is the checker."""
+    from evenvizion_amd._lib import Context
+    rng = np.random.default_rng(8)
+    A = (rng.integers(0, 2, 112) * 255).astype(np.int32)
+    nq, nt = 300, 700
+    q = np.full((nq, 128), 128, np.int32)
+    for i in range(nq):
+        row = A.copy(); ii = rng.choice(112, rng.integers(0, 9), replace=False); row[ii] = 255 - row[ii]; q[i, 16:] = row
+    t = np.full((nt, 128), 128, np.int32); t[:, 16:] = 255 - A
+    for j in range(nt):
+        k = (j * 7 + 3) % 5
+        pos = rng.choice(16, k, replace=False); t[j, pos] += rng.choice([-1, 1], k)
+    q = q.astype(np.uint8); t = t.astype(np.uint8)
+    D = ((q[:, None, :].astype(np.int64) - t[None, :, :].astype(np.int64)) ** 2).sum(-1)
+    oi, od = O.knn2_f32(q.astype(np.float32), t.astype(np.float32))
+    assert D.min() > (1 << 22) and (np.argsort(D, axis=1, kind="stable")[:, :2] != oi).any(axis=1).sum() > 50
+    c = Context(device=0, max_w=64, max_h=64, max_features=500, max_frames=2)
+    try:
+        idx = torch.zeros(nq, 2, dtype=torch.int32, device="cuda")
+        d2 = torch.zeros(nq, 2, dtype=torch.int32, device="cuda")
+        c.knn2(dev(q), dev(t), idx, d2)
+        c.synchronize()
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.array_equal(np.sqrt(d2.cpu().numpy().astype(np.uint32).astype(np.float32)), od)
+    finally:
+        c.close()

@@ -1,0 +1,31 @@
+"""Multi-type stream probe: one synthetic stream through evh_stream_homography_batch_types (the reference's default
+FrameProcessing list SURF, SIFT, ORB and its sub-lists), 32 pairs per call.
+usage: python tools/types_probe.py [WxH ...]   (default 400x224 = the reference's default resize_width)"""
+import os, sys, time, json
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np, torch
+from evenvizion_amd import synthetic as S
+from evenvizion_amd._lib import Context
+res = {}
+for wh in (sys.argv[1:] or ["400x224"]):
+    w, h = map(int, wh.split("x"))
+    nfr = 33
+    frames, _ = S.make_stream(11, 9, w, h)
+    frames = np.concatenate([frames] * 4)[:nfr]
+    d = torch.from_numpy(S.gray_to_bgr(frames)).cuda()
+    ctx = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=nfr)
+    ctx.sift_enable(6144 if w <= 640 else 40960); ctx.surf_enable(4096 if w <= 640 else 16384)
+    for feats in (["ORB"], ["SIFT"], ["SURF"], ["SURF", "SIFT", "ORB"]):
+        if w > 640 and feats != ["ORB"] and "SIFT" in feats:
+            continue   # the matching filter bounds a type at 7 680 key points per frame
+        H = torch.zeros(nfr - 1, 9, dtype=torch.float64, device='cuda'); st = torch.zeros(nfr - 1, dtype=torch.int32, device='cuda')
+        ctx.stream_homography_batch_types(d, H, st, feats); ctx.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            ctx.stream_homography_batch_types(d, H, st, feats)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t) / 3
+        res['%dx%d_%s' % (w, h, "+".join(feats))] = dict(pairs=nfr - 1, seconds=round(dt, 4), pairs_per_s=round((nfr - 1) / dt, 1),
+                                                         ok=int((st == 0).sum()))
+    ctx.close()
+print(json.dumps(res, indent=1))
