@@ -144,6 +144,50 @@ def test_bench_gather_path_world2():
     assert res == [(0, True), (1, True)]
 
 
+# ---- BASELINE configs[4] shape: one stream PER RANK, chunked, each rank carrying its own {H_sup, H_prev}; per step one
+# all_gather of the ranks' H records (bench.py --config 5) ------------------------------------------------------------
+def _per_rank_stream_worker(rank, world, port, B, nsteps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def chunk_result(r, step, state):
+        """stand-in for Context.stream_homography_batch on rank r's own stream: an order-dependent running quantity
+        carried in `state` between chunks (what the device keeps in state_in / state_out)"""
+        H = torch.zeros(B, 9, dtype=torch.float64)
+        for k in range(B):
+            state = state * 1.0001 + (r + 1) * 0.5 + step * B + k
+            H[k] = state
+        return H, state
+
+    ok = True
+    state = torch.zeros((), dtype=torch.float64)
+    want_states = [torch.zeros((), dtype=torch.float64) for _ in range(world)]
+    gathered = torch.zeros(world * B, 9, dtype=torch.float64)
+    for step in range(nsteps):
+        H, state = chunk_result(rank, step, state)
+        dist.all_gather_into_tensor(gathered, H)
+        for r in range(world):                       # every rank holds every stream's chunk, in rank order
+            Hw, want_states[r] = chunk_result(r, step, want_states[r])
+            ok = ok and bool(torch.equal(gathered[r * B:(r + 1) * B], Hw))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_stream_per_rank_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_per_rank_stream_worker, args=(r, 2, port, 16, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
 # ---- the same two paths over RCCL on real devices: needs two GPUs (the driver's 8-GPU node; skipped on a 1-GPU box) ----
 def _nccl_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
