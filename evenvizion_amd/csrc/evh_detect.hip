@@ -168,6 +168,88 @@ __global__ __launch_bounds__(256) void k_pyr_down(uint8_t* __restrict__ pyr, int
   }
 }
 
+// K2, row-walking form (round 3).  Same arithmetic as k_pyr_down, different work split: a workgroup owns a 256 x 32 output
+// tile, a WAVE owns 8 consecutive output rows of it and a lane 4 output columns.  At scale 1.2 consecutive output rows
+// share a source row five times out of six: the wave walks down its rows keeping the horizontal pass h(row) of the two
+// source rows in registers and recomputes only the row that is new (10.6 horizontal row-passes per 8 output rows
+// instead of 16; the row index is wave-uniform, so the reuse test is a scalar branch and the y tables come through
+// scalar loads).  VALU slots per output quad 52 -> 41, LDS byte reads 16 -> 10.6; results bit-identical.
+#define PW_W 256
+#define PW_H 32
+#define PW_SW 352                        // staged source row bytes: >= 1.21*256 + 15 + 2, multiple of 16
+#define PW_SH (PW_H * 121 / 100 + 5)     // staged source rows
+__global__ __launch_bounds__(256) void k_pyr_walk(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t src_off,
+                                                  int src_stride, int64_t dst_off, int dst_stride, int dw, int dh,
+                                                  int tiles_x, int tx_magic, int ntiles, int nframes,
+                                                  const int* __restrict__ xofs, const int* __restrict__ xc1,
+                                                  const int* __restrict__ yofs, const int* __restrict__ yc1) {
+  __shared__ uint32_t tile32[PW_SH * PW_SW / 4];
+  int f, bt;
+  xcd_order(bt, f);
+  if (bt >= ntiles || f >= nframes) return;             // grid padding (workgroup-uniform)
+  const int ty = div_magic20(bt, tx_magic), tx = bt - ty * tiles_x;
+  const int x0 = tx * PW_W, y0 = ty * PW_H;
+  const int x1 = min(x0 + PW_W, dw) - 1, y1 = min(y0 + PW_H, dh) - 1;
+  const int sx0 = xofs[x0] & ~15, sy0 = yofs[y0];
+  const int ex = xofs[x1] + 1, ey = yofs[y1] + 1;
+  const int ncol16 = (ex - sx0) / 16 + 1, nrow = ey - sy0 + 1;     // <= PW_SW/16 = 22, <= PW_SH
+  uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;
+  const uint8_t* simg = base + src_off + sx0;
+  uint8_t* dimg = base + dst_off;
+  // this lane's four columns: tap offset inside the staged row and the right-tap weight
+  const int lane = threadIdx.x & 63;
+  const int x = x0 + lane * 4;
+  int o[4]; uint32_t c1[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int xi = min(x + i, dw - 1);
+    o[i] = xofs[xi] - sx0; c1[i] = (uint32_t)xc1[xi];
+  }
+  {
+    const int c16 = threadIdx.x & 31;                   // 32 threads per source row, <= 22 of them move a 16-byte cell
+    if (c16 < ncol16) {
+      const uint4* col = reinterpret_cast<const uint4*>(simg) + c16;
+      const int stride16 = src_stride >> 4;
+      for (int r = threadIdx.x >> 5; r < nrow; r += 8)
+        *reinterpret_cast<uint4*>(&tile32[r * (PW_SW / 4) + c16 * 4]) = col[mad24((uint32_t)(sy0 + r), (uint32_t)stride16, 0u)];
+    }
+  }
+  __syncthreads();
+  const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int yb = y0 + w * (PW_H / 4);
+  uint32_t h0[4] = {0, 0, 0, 0}, h1[4] = {0, 0, 0, 0};
+  auto hpass = [&](int r, uint32_t (&h)[4]) {           // horizontal pass of staged source row r on this lane's columns
+    const uint8_t* row = tile + r * PW_SW;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t a = row[o[i]], b = row[o[i] + 1];
+      h[i] = mad24(a, 256u - c1[i], mad24(b, c1[i], 0u));
+    }
+  };
+  int prev = -9;
+#pragma unroll
+  for (int rr = 0; rr < PW_H / 4; rr++) {
+    const int y = yb + rr;
+    if (y >= dh) break;                                  // wave-uniform
+    const int r = yofs[y] - sy0;                         // scalar loads: y is wave-uniform
+    const uint32_t m1 = (uint32_t)yc1[y], m0 = 256u - m1;
+    if (r == prev + 1) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) h0[i] = h1[i];
+      hpass(r + 1, h1);
+    } else if (r != prev) {
+      hpass(r, h0); hpass(r + 1, h1);
+    }
+    prev = r;
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = mad24(h0[i], m0, mad24(h1[i], m1, 32768u));
+    const uint32_t out = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020C0Cu);
+    if (x < dw) reinterpret_cast<uint32_t*>(dimg)[mad24((uint32_t)y, (uint32_t)(dst_stride >> 2), (uint32_t)(x >> 2))] = out;
+  }
+}
+
 // K1+K2 fused for level 1: a workgroup owns one 128 x 32 tile of level 1. It converts the level-0 footprint of that
 // tile straight from the BGR/gray input into LDS (gray never re-read from HBM), writes the level-0 pixels it OWNS
 // (columns [xofs[x0] & ~3, xofs[x0 + 128] & ~3), rows [yofs[y0], yofs[y0 + 32]); the monotone tap tables make these
@@ -1291,14 +1373,25 @@ int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int
 }
 
 int evh_launch_pyramid(evh_ctx* c, int nframes) {
+  static const bool old_form = getenv("EVH_PYR_OLD") != nullptr;     // A/B aid: the round-2 kernel (k_pyr_down, 128 x 64 tiles)
   for (int l = c->level1_fused ? 2 : 1; l < EVH_NLEVELS; l++) {
     const EvhLevel& S = c->g.lv[l - 1];
     const EvhLevel& D = c->g.lv[l];
-    const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PDN_H - 1) / PDN_H;
     const int* t = c->d_tabs + D.tab_off;   // xofs | xc1 | yofs | yc1 (linear_exact_tab in evh_api.hip)
-    hipLaunchKernelGGL(k_pyr_down, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
-                       c->g.pyr_frame_bytes, S.off, S.stride, D.off, D.stride, D.w, D.h, tiles_x,
-                       magic20(tiles_x), tiles_x * tiles_y, nframes, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
+    // the row-walking kernel stages <= 1.21 x its tile: ORB's levels shrink by 1.2 (a first level built from a
+    // resized frame never comes here: level 0 -> 1 has the same ratio)
+    const bool walk = !old_form && (int64_t)S.w * 100 <= (int64_t)D.w * 121 && (int64_t)S.h * 100 <= (int64_t)D.h * 121;
+    if (walk) {
+      const int tiles_x = (D.w + PW_W - 1) / PW_W, tiles_y = (D.h + PW_H - 1) / PW_H;
+      hipLaunchKernelGGL(k_pyr_walk, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
+                         c->g.pyr_frame_bytes, S.off, S.stride, D.off, D.stride, D.w, D.h, tiles_x,
+                         magic20(tiles_x), tiles_x * tiles_y, nframes, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
+    } else {
+      const int tiles_x = (D.w + PD_W - 1) / PD_W, tiles_y = (D.h + PDN_H - 1) / PDN_H;
+      hipLaunchKernelGGL(k_pyr_down, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
+                         c->g.pyr_frame_bytes, S.off, S.stride, D.off, D.stride, D.w, D.h, tiles_x,
+                         magic20(tiles_x), tiles_x * tiles_y, nframes, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h);
+    }
     EVH_HIP(c, hipGetLastError());
   }
   return EVH_SUCCESS;
