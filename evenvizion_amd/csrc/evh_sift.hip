@@ -649,7 +649,7 @@ int evh_sift_allocate(evh_ctx* c, int max_sift_features) {
   const int cap = (max_sift_features + 63) & ~63;
   const size_t F = (size_t)c->max_frames;
   int rc;
-#define S_(call) if ((rc = (call)) != EVH_SUCCESS) return rc
+#define S_(call) if ((rc = (call)) != EVH_SUCCESS) { evh_sift_free(c); return rc; }   /* a partial allocation is released */
   S_(salloc(c, &c->d_sift_pyr, (size_t)group * gm.frame_floats + 64));
   S_(salloc(c, &c->d_sift_tmp, (size_t)group * gm.tmp_floats + 64));
   S_(salloc(c, &c->d_sift_cand, F * 4 * cap));
@@ -674,6 +674,9 @@ void evh_sift_free(evh_ctx* c) {
   void* ptrs[] = {c->d_sift_pyr, c->d_sift_tmp, c->d_sift_cand, c->d_sift_ncand, c->d_sift_raw, c->d_sift_nraw, c->d_sift_srt,
                   c->d_sift_kp, c->d_sift_xy, c->d_sift_desc, c->d_sift_count, c->d_sift_flags};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  c->d_sift_pyr = nullptr; c->d_sift_tmp = nullptr; c->d_sift_cand = nullptr; c->d_sift_ncand = nullptr; c->d_sift_raw = nullptr;
+  c->d_sift_nraw = nullptr; c->d_sift_srt = nullptr; c->d_sift_kp = nullptr; c->d_sift_xy = nullptr; c->d_sift_desc = nullptr;
+  c->d_sift_count = nullptr; c->d_sift_flags = nullptr; c->sift_cap = 0;
 }
 
 // SIFT on the frames whose gray level 0 is resident in the context's ORB pyramid (evh_launch_gray_level0 /

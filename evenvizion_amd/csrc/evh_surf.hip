@@ -584,7 +584,7 @@ int evh_surf_allocate(evh_ctx* c, int max_surf_features) {
   const int cap = (max_surf_features + 63) & ~63;
   const size_t F = (size_t)c->max_frames;
   int rc;
-#define S_(call) if ((rc = (call)) != EVH_SUCCESS) return rc
+#define S_(call) if ((rc = (call)) != EVH_SUCCESS) { evh_surf_free(c); return rc; }   /* a partial allocation is released */
   S_(salloc(c, &c->d_surf_tabs, sizeof(SurfTabs)));
   S_(salloc(c, &c->d_surf_sum, (size_t)group * sum_ints + 64));
   S_(salloc(c, &c->d_surf_det, (size_t)group * det_floats + 64));
@@ -609,6 +609,9 @@ void evh_surf_free(evh_ctx* c) {
   void* ptrs[] = {c->d_surf_tabs, c->d_surf_sum, c->d_surf_det, c->d_surf_trace, c->d_surf_raw, c->d_surf_nraw, c->d_surf_srt,
                   c->d_surf_kp, c->d_surf_xy, c->d_surf_desc, c->d_surf_count, c->d_surf_flags};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  c->d_surf_tabs = nullptr; c->d_surf_sum = nullptr; c->d_surf_det = nullptr; c->d_surf_trace = nullptr; c->d_surf_raw = nullptr;
+  c->d_surf_nraw = nullptr; c->d_surf_srt = nullptr; c->d_surf_kp = nullptr; c->d_surf_xy = nullptr; c->d_surf_desc = nullptr;
+  c->d_surf_count = nullptr; c->d_surf_flags = nullptr; c->surf_cap = 0;
 }
 
 // SURF on the frames whose gray level 0 is resident in the context's ORB pyramid

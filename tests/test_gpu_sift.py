@@ -362,3 +362,28 @@ def test_byte_matcher_on_128_byte_rows_ties_after_sqrt():
         assert np.array_equal(np.sqrt(d2.cpu().numpy().astype(np.uint32).astype(np.float32)), od)
     finally:
         c.close()
+
+
+def test_detector_slot_overflow_is_a_pair_status_in_the_fused_path():
+    """A frame with more SIFT key points than evh_sift_enable reserved fails ITS pairs with EVH_PAIR_CAPACITY (6) in the
+    fused multi-type entries -- never a silent truncation -- and only the pairs that touch it."""
+    from evenvizion_amd._lib import PAIR_CAPACITY
+    w, h = 400, 224
+    fr, _ = S.make_stream(53, 4, w, h)
+    sparse = np.full((h, w), 100, np.uint8)                 # 65 bright squares: 260 key points, the textured frames have ~2 400
+    for y in range(50, 170, 24):
+        for x in range(50, 350, 24):
+            sparse[y:y + 7, x:x + 7] = 220
+    frames = np.stack([sparse, np.roll(sparse, 2, axis=1), fr[0], fr[1]])
+    n_sparse = len(O.sift_detect(sparse)["xy"])
+    assert 0 < n_sparse < 500 and len(O.sift_detect(fr[0])["xy"]) > 1024
+    c = make_ctx(w, h, frames=4, sift=512)
+    try:
+        H = torch.zeros(3, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch_types(dev(frames), H, st, ["SIFT"])
+        c.synchronize()
+        got = st.cpu().numpy()
+        assert got[1] == PAIR_CAPACITY and got[2] == PAIR_CAPACITY and got[0] == 0
+    finally:
+        c.close()
