@@ -123,6 +123,12 @@ def _make_pair_job(a):
 def make_unique_pairs(config_seed, U, w, h, nproc=0):
     """U distinct synthetic pairs (SURVEY 8d seeds 1000*config + pair index), generated on the host cores in parallel."""
     import multiprocessing as mp
+    # EVH_BENCH_CACHE=<dir>: keep the generated frames between runs on one box (the profiling passes of
+    # tools/collect_profiles.sh run the same workload six times; under rocprofv3 the generator may not fork)
+    cache = os.environ.get("EVH_BENCH_CACHE")
+    cache_file = os.path.join(cache, "pairs_seed%d_%dx%d_u%d.npy" % (config_seed, w, h, U)) if cache else None
+    if cache_file and os.path.exists(cache_file):
+        return np.load(cache_file, allow_pickle=False)
     jobs = [(1000 * config_seed + p, w, h) for p in range(U)]
     if nproc <= 0:
         nproc = min(U, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8,
@@ -135,6 +141,9 @@ def make_unique_pairs(config_seed, U, w, h, nproc=0):
     gray = np.empty((2 * U, h, w), np.uint8)
     for p, (a, b, _) in enumerate(res):
         gray[2 * p] = a; gray[2 * p + 1] = b
+    if cache_file:
+        os.makedirs(cache, exist_ok=True)
+        np.save(cache_file, gray)
     return gray
 
 

@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export EVH_BENCH_CACHE=/tmp/evh_bench_cache     # the 64 synthetic pairs are generated once (in parallel, outside the profiler)
+(cd $R && python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --skip-no-temporal > $O/prime.json 2> $O/prime.err)
 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --gen-procs 1 --unique 64 --skip-no-temporal > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/write.log 2>&1
@@ -16,4 +18,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 # the stream workload (BASELINE configs[2]): kernel stats only
 rocprofv3 --kernel-trace --stats -d $O/stats3 -o stats3 --output-format csv -- python3 $R/bench.py --config 3 --steps 4 --warmup 1 --cpu-pairs 0 > $O/stats3.log 2>&1
 cd $R && python bench.py > $O/bench.json 2> $O/bench.err
+for c in 2 3 4 5; do python bench.py --config $c > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err || true; done
 tail -1 $O/bench.json
