@@ -271,7 +271,6 @@ int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int s
 // ---- multi-type pairs (frame_processing.py:91-104) ---------------------------------------------------------------------------
 int ensure_multitype(evh_ctx* c) {
   if (c->mt.cap) return EVH_SUCCESS;
-  if (!c->sift_cap && !c->surf_cap) return evh_fail(c, EVH_ERR_INVALID, "feature types beyond ORB need evh_sift_enable / evh_surf_enable first");
   const int each = std::max(c->kcap, std::max(c->sift_cap, c->surf_cap)), cap = c->kcap + c->sift_cap + c->surf_cap;
   if ((size_t)each * 5 * sizeof(int) > 150 * 1024)
     return evh_fail(c, EVH_ERR_CAPACITY, "multi-type pairs: at most 7680 key points per frame and type in the matching filter");

@@ -205,19 +205,32 @@ __global__ __launch_bounds__(256) void k_pyr_walk(uint8_t* __restrict__ pyr, int
     const int xi = min(x + i, dw - 1);
     o[i] = xofs[xi] - sx0; c1[i] = (uint32_t)xc1[xi];
   }
+  // this wave's eight output rows: source row and bottom-tap weight, fetched (scalar loads: the row index is
+  // wave-uniform) before the staging loads so that the row loop below never waits on memory
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int yb = y0 + w * (PW_H / 4);
+  int yo[PW_H / 4]; uint32_t ym[PW_H / 4];
+#pragma unroll
+  for (int rr = 0; rr < PW_H / 4; rr++) {
+    const int yi = min(yb + rr, dh - 1);
+    yo[rr] = yofs[yi] - sy0; ym[rr] = (uint32_t)yc1[yi];
+  }
   {
-    const int c16 = threadIdx.x & 31;                   // 32 threads per source row, <= 22 of them move a 16-byte cell
-    if (c16 < ncol16) {
-      const uint4* col = reinterpret_cast<const uint4*>(simg) + c16;
-      const int stride16 = src_stride >> 4;
-      for (int r = threadIdx.x >> 5; r < nrow; r += 8)
-        *reinterpret_cast<uint4*>(&tile32[r * (PW_SW / 4) + c16 * 4]) = col[mad24((uint32_t)(sy0 + r), (uint32_t)stride16, 0u)];
-    }
+    // 32 threads per source row, <= 22 of them move a 16-byte cell; ALL of a thread's cells (<= 6 rows, 8 apart) are
+    // requested before the first is stored: one memory round trip per workgroup
+    const int c16 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    const uint4* col = reinterpret_cast<const uint4*>(simg) + c16;
+    const int stride16 = src_stride >> 4;
+    uint4 v[(PW_SH + 7) / 8];
+#pragma unroll
+    for (int k = 0; k < (PW_SH + 7) / 8; k++)
+      if (c16 < ncol16 && r0 + 8 * k < nrow) v[k] = col[mad24((uint32_t)(sy0 + r0 + 8 * k), (uint32_t)stride16, 0u)];
+#pragma unroll
+    for (int k = 0; k < (PW_SH + 7) / 8; k++)
+      if (c16 < ncol16 && r0 + 8 * k < nrow) *reinterpret_cast<uint4*>(&tile32[(r0 + 8 * k) * (PW_SW / 4) + c16 * 4]) = v[k];
   }
   __syncthreads();
   const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int yb = y0 + w * (PW_H / 4);
   uint32_t h0[4] = {0, 0, 0, 0}, h1[4] = {0, 0, 0, 0};
   auto hpass = [&](int r, uint32_t (&h)[4]) {           // horizontal pass of staged source row r on this lane's columns
     const uint8_t* row = tile + r * PW_SW;
@@ -232,8 +245,8 @@ __global__ __launch_bounds__(256) void k_pyr_walk(uint8_t* __restrict__ pyr, int
   for (int rr = 0; rr < PW_H / 4; rr++) {
     const int y = yb + rr;
     if (y >= dh) break;                                  // wave-uniform
-    const int r = yofs[y] - sy0;                         // scalar loads: y is wave-uniform
-    const uint32_t m1 = (uint32_t)yc1[y], m0 = 256u - m1;
+    const int r = yo[rr];
+    const uint32_t m1 = ym[rr], m0 = 256u - m1;
     if (r == prev + 1) {
 #pragma unroll
       for (int i = 0; i < 4; i++) h0[i] = h1[i];
