@@ -221,13 +221,23 @@ __global__ __launch_bounds__(256) void k_pyr_walk(uint8_t* __restrict__ pyr, int
     const int c16 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
     const uint4* col = reinterpret_cast<const uint4*>(simg) + c16;
     const int stride16 = src_stride >> 4;
-    uint4 v[(PW_SH + 7) / 8];
-#pragma unroll
-    for (int k = 0; k < (PW_SH + 7) / 8; k++)
-      if (c16 < ncol16 && r0 + 8 * k < nrow) v[k] = col[mad24((uint32_t)(sy0 + r0 + 8 * k), (uint32_t)stride16, 0u)];
-#pragma unroll
-    for (int k = 0; k < (PW_SH + 7) / 8; k++)
-      if (c16 < ncol16 && r0 + 8 * k < nrow) *reinterpret_cast<uint4*>(&tile32[(r0 + 8 * k) * (PW_SW / 4) + c16 * 4]) = v[k];
+    // (clamped addresses, unconditional loads: the six values stay in registers; the stores carry the bounds)
+    const uint4* colc = reinterpret_cast<const uint4*>(simg) + min(c16, ncol16 - 1);
+    uint4 v0, v1, v2, v3, v4, v5;
+    static_assert((PW_SH + 7) / 8 == 6, "six staged rows per thread");
+#define PW_LD(k) colc[mad24((uint32_t)(sy0 + min(r0 + 8 * (k), nrow - 1)), (uint32_t)stride16, 0u)]
+    v0 = PW_LD(0); v1 = PW_LD(1); v2 = PW_LD(2); v3 = PW_LD(3); v4 = PW_LD(4); v5 = PW_LD(5);
+#undef PW_LD
+    (void)col;
+    if (c16 < ncol16) {
+      uint4* d = reinterpret_cast<uint4*>(&tile32[r0 * (PW_SW / 4) + c16 * 4]);
+      if (r0 < nrow) d[0] = v0;
+      if (r0 + 8 < nrow) d[8 * (PW_SW / 16)] = v1;
+      if (r0 + 16 < nrow) d[16 * (PW_SW / 16)] = v2;
+      if (r0 + 24 < nrow) d[24 * (PW_SW / 16)] = v3;
+      if (r0 + 32 < nrow) d[32 * (PW_SW / 16)] = v4;
+      if (r0 + 40 < nrow) d[40 * (PW_SW / 16)] = v5;
+    }
   }
   __syncthreads();
   const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
