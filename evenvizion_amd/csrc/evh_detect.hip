@@ -491,6 +491,7 @@ struct FastLds {
   // queue is dead before NMS writes the list.
   uint32_t lst[FS_H * FS_DW + 4];
   uint16_t scored[FT_W * FT_H / 2];  // lifted path: pixels whose exact score reached T
+  alignas(16) uint32_t sink[4];      // target of the second staging store of threads that have no second item
   int lcnt, gbase, qcnt, scnt;
 };
 
@@ -503,21 +504,32 @@ __device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const
   // so an item is wholly inside [0, stride) or wholly outside.
   static_assert(FR_DW % 4 == 0 && ((EVH_FAST_OX - 8) % 16) == 0 && (FT_W % 16) == 0, "16-byte staging");
   constexpr int C16 = FR_DW / 4;
+  constexpr int NITEM = FR_H * C16;                     // 324 items: two per thread at most
+  static_assert(NITEM > 256 && NITEM <= 512, "two staging items per thread");
   const int stride16 = L.stride >> 4;
   // workgroup-uniform: every staged byte exists (all tiles but those on the right / bottom edge of a level)
   const bool inside = y0 >= 4 && y0 + FT_H + 4 <= L.h && x0 >= 8 && x0 + FT_W + 8 <= L.stride;
-  int r = (int)threadIdx.x / C16, c16 = (int)threadIdx.x - r * C16;
-  const uint4* p0 = reinterpret_cast<const uint4*>(img) + mad24s(y0 - 4, stride16, (x0 - 8) >> 4);
-#pragma unroll
-  for (int j = 0; j < (FR_H * C16 + 255) / 256; j++) {
-    if (j * 256 + (int)threadIdx.x < FR_H * C16) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      const int y = y0 - 4 + r, x = x0 - 8 + c16 * 16;
-      if (inside || (x >= 0 && x < L.stride && y >= 0 && y < L.h)) v = p0[mad24s(r, stride16, c16)];
-      *reinterpret_cast<uint4*>(&S.raw[r * FR_DW + c16 * 4]) = v;
-    }
-    r += 256 / C16; c16 += 256 % C16;
-    if (c16 >= C16) { c16 -= C16; r++; }
+  const int ra = (int)threadIdx.x / C16, ca = (int)threadIdx.x - ra * C16;
+  int rb = ra + 256 / C16, cb = ca + 256 % C16;
+  if (cb >= C16) { cb -= C16; rb++; }
+  const bool has_b = (int)threadIdx.x + 256 < NITEM;
+  const uint4* img16 = reinterpret_cast<const uint4*>(img);
+  // BOTH items are requested before either is stored (clamped addresses, unconditional loads: one memory round trip
+  // per workgroup -- the predicated form compiled to load, wait, store, load, wait, store)
+  const int ya = y0 - 4 + ra, xa = x0 - 8 + ca * 16, yb = y0 - 4 + rb, xb = x0 - 8 + cb * 16;
+  const int xmax = L.stride - 16;
+  const uint4 la = img16[mad24s(min(max(ya, 0), L.h - 1), stride16, min(max(xa, 0), xmax) >> 4)];
+  const uint4 lb = img16[mad24s(min(max(yb, 0), L.h - 1), stride16, min(max(xb, 0), xmax) >> 4)];
+  // straight-line stores (a thread without a second item writes it to a sink word): nothing between the two loads and
+  // the two stores for the compiler to sink a load into
+  uint4* da = reinterpret_cast<uint4*>(&S.raw[ra * FR_DW + ca * 4]);
+  uint4* db = has_b ? reinterpret_cast<uint4*>(&S.raw[rb * FR_DW + cb * 4]) : reinterpret_cast<uint4*>(S.sink);
+  *da = la;
+  *db = lb;
+  if (!inside) {                                          // edge tiles (workgroup-uniform): what lies outside the level reads as 0
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    if (!(xa >= 0 && xa < L.stride && ya >= 0 && ya < L.h)) *da = z;
+    if (has_b && !(xb >= 0 && xb < L.stride && yb >= 0 && yb < L.h)) *db = z;
   }
 }
 
