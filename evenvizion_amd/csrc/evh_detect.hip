@@ -1260,17 +1260,22 @@ __global__ __launch_bounds__(64 * DW_PER_BLOCK, 8) void k_describe(DescribeArgs 
   const int xs = cx - DP_R, xa = xs & ~15, shq = (xs - xa) >> 2;
   const uint32_t sh = (uint32_t)(xs & 3);
   {
+    // 45 rows x 4 cells = 180 cells, lane = (row & 15, cell) three times over; the third round covers rows 32..47: its
+    // loads are clamped to row 44 and its stores of rows 45..47 land in the part of the wave's region the raw form does
+    // not use -- no predicate, so all three requests are in flight before the first store (the predicated form
+    // compiled to two loads, wait, third load, wait)
+    static_assert(47 * DP_STRIDE4 + 16 <= (DP_N * DH_STRIDE + 2) / 2 + 1, "rows 45..47 fit behind the raw patch");
     const uint4* src = reinterpret_cast<const uint4*>(img + xa);
     const int stride16 = L.stride >> 4;
+    const int r0 = lane >> 2, c = lane & 3;
+    uint4 v[3];
 #pragma unroll
-    for (int k = 0; k < (DP_N * 4 + 63) / 64; k++) {
-      const int i = lane + 64 * k;
-      if (i < DP_N * 4) {
-        const int r = i >> 2, c = i & 3;
-        const uint4 v = src[mad24((uint32_t)(cy - DP_R + r), (uint32_t)stride16, (uint32_t)c)];
-        uint32_t* d = raw + r * DP_STRIDE4 + c * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
+    for (int k = 0; k < 3; k++)
+      v[k] = src[mad24((uint32_t)(cy - DP_R + min(r0 + 16 * k, DP_N - 1)), (uint32_t)stride16, (uint32_t)c)];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      uint32_t* d = raw + (r0 + 16 * k) * DP_STRIDE4 + c * 4;
+      d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
     }
   }
 #define WAVE_LDS_SYNC()                                    \
