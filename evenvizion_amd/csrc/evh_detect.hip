@@ -492,13 +492,13 @@ struct FastLds {
   uint32_t lst[FS_H * FS_DW + 4];
   uint16_t scored[FT_W * FT_H / 2];  // lifted path: pixels whose exact score reached T
   alignas(16) uint32_t sink[4];      // target of the second staging store of threads that have no second item
-  int lcnt, gbase, qcnt, scnt;
+  int lcnt, gbase, qcnt, scnt, q1cnt;
 };
 
 // stage rows y0-4 .. y0+FT_H+3, columns x0-8 .. x0+135 with 16-byte loads (data outside the image reads as 0: it
 // only feeds pixels whose centre is outside the testable range, which are never scored); clears the counters
 __device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const EvhLevel& L, int x0, int y0) {
-  if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; S.scnt = 0; }
+  if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; S.scnt = 0; S.q1cnt = 0; }
   // 16-byte items (x0 - 8 = 16 + 128 tx is 16-byte aligned, a staged row is 9 of them): item i = (row i / 9,
   // column i % 9), 324 items = 2 per thread at most; +256 items = +28 rows +4 columns.  Rows are padded to 64 bytes,
   // so an item is wholly inside [0, stride) or wholly outside.
@@ -593,6 +593,23 @@ __device__ __forceinline__ uint32_t pretest_pass4(uint32_t c, uint32_t rd, uint3
   return BITOP3(Dm, Bm, H, (A | B) & C);
 }
 
+// the vertical ring pair alone (points 0 and 8): every 9-arc holds one of them, so "neither differs from the centre by
+// more than T" rejects exactly.  First level of the two-level variant (EVH_FAST_TWO_LEVEL, an A/B build: see
+// profiles/r03_fast_two_level_ab.txt); half the comparison network and no v_alignbyte.
+__device__ __forceinline__ uint32_t vert_pass4(uint32_t c, uint32_t rd, uint32_t ru, uint32_t K4) {
+  const uint32_t H = 0x80808080u, Lm = 0x7F7F7F7Fu;
+  const uint32_t t = (c | H) - K4;
+  const uint32_t cl = BITOP3(t, c, Lm, A & (B | C));
+  const uint32_t u = (c & Lm) + K4;
+  const uint32_t ch = BITOP3(u, c, H, A | (B & C));
+  const uint32_t clH = cl | H, chL = ch & Lm;
+  const uint32_t D0 = swar_ge(clH, cl, rd, rd & Lm), D8 = swar_ge(clH, cl, ru, ru & Lm);
+  const uint32_t B0 = swar_ge(rd | H, rd, ch, chL), B8 = swar_ge(ru | H, ru, ch, chL);
+  const uint32_t Dm = BITOP3(D0 | D8, c, t, A & (B | C));
+  const uint32_t Bm = BITOP3(B0 | B8, c, u, A & ~(B & C));
+  return BITOP3(Dm, Bm, H, (A | B) & C);
+}
+
 // lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
 // compass points), four pixels per 32-bit operation; a quad with at least one passing pixel is queued
 // (quad index | pass bits << 16).  Phase B: exact score of the queued pixels, 4 lanes per queued quad.
@@ -607,6 +624,69 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
   static_assert((FS_H * FS_DW) % 4 == 0 && FS_H * FS_DW <= 1024, "one 16-byte store per thread clears the score plane");
   if (threadIdx.x < FS_H * FS_DW / 4)                           // phase B overwrites the bytes that reach T
     reinterpret_cast<uint4*>(S.score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef EVH_FAST_TWO_LEVEL
+  {
+    // level 1: the vertical pair on every quad; survivors (quad index) -> q1, which lives in the words of S.scored (dead
+    // until phase B)
+    uint16_t* q1 = S.scored;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = threadIdx.x + 256 * k;
+      P[k] = 0;
+      if (i < FS_H * FS_DW) {
+        const uint32_t* p = S.raw + mad24((uint32_t)(sr + 3), FR_DW, (uint32_t)sq);
+        P[k] = vert_pass4(p[1], p[1 + 3 * FR_DW], p[1 - 3 * FR_DW], K4);
+      }
+      sr += 7; sq += 18;
+      if (sq >= FS_DW) { sq -= FS_DW; sr++; }
+    }
+    {
+      const unsigned long long m0 = __ballot(P[0] != 0), m1 = __ballot(P[1] != 0), m2 = __ballot(P[2] != 0),
+                               m3 = __ballot(P[3] != 0);
+      const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), tot = n0 + n1 + n2 + __popcll(m3);
+      if (tot) {
+        int base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&S.q1cnt, tot);
+        base = __builtin_amdgcn_readfirstlane(base);
+#define FQ1_PUSH(k, off, m)                                                                                             \
+        if (P[k]) q1[base + (off) + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32),                               \
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))] =    \
+            (uint16_t)(threadIdx.x + 256 * (k))
+        FQ1_PUSH(0, 0, m0); FQ1_PUSH(1, n0, m1); FQ1_PUSH(2, n0 + n1, m2); FQ1_PUSH(3, n0 + n1 + n2, m3);
+#undef FQ1_PUSH
+      }
+    }
+    __syncthreads();
+    // level 2: the full four-point test on the survivors, then the quad queue of phase B as before
+    const int n1 = S.q1cnt;
+    for (int e0 = 0; e0 < n1; e0 += 256) {             // workgroup-uniform
+      const int e = e0 + (int)threadIdx.x;
+      uint32_t Pq = 0; int qi = 0;
+      if (e < n1) {
+        qi = q1[e];
+        const int sr2 = qi / FS_DW, sq2 = qi - sr2 * FS_DW;
+        uint32_t cmask = 0x80808080u;
+        if (!interior) {
+          const int y = y0 - 1 + sr2, xq = x0 - 4 + sq2 * 4;
+          const bool rowok = y >= 3 && y < L.h - 3;
+          const int lo = min(max(3 - xq, 0), 4), hi = max(min(L.w - 3 - xq, 4), 0);
+          cmask = (rowok && lo < hi) ? (0x80808080u << (8 * lo)) & (0x80808080u >> (8 * (4 - hi))) : 0u;
+        }
+        const uint32_t* p = S.raw + mad24((uint32_t)(sr2 + 3), FR_DW, (uint32_t)sq2);
+        const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
+        Pq = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu, __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4) & cmask;
+      }
+      const unsigned long long m = __ballot(Pq != 0);
+      if (m) {
+        int base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&S.qcnt, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (Pq) S.lst[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+            (uint32_t)qi | (((Pq >> 7) | (Pq >> 22)) << 16);
+      }
+    }
+  }
+#else
   // two copies of the loop: the interior one (most tiles) is straight-line code, so the LDS reads of its four quads
   // can be issued together instead of each behind its own range test
   auto quads = [&](auto interior_tag) {
@@ -653,6 +733,7 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
 #undef FQ_PUSH
     }
   }
+#endif
   __syncthreads();
   const int nq = S.qcnt;
   const uint8_t* rawb = reinterpret_cast<const uint8_t*>(S.raw);
