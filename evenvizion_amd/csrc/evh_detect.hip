@@ -419,6 +419,11 @@ struct FastArgs {
 #define FR_H (FT_H + 8)          // staged raw rows: y0-4 .. y0+FT_H+3
 #define FS_DW ((FT_W + 8) / 4)   // score row: x0-4 .. x0+131, 34 quads (dwords of 4 byte scores)
 #define FS_H (FT_H + 2)          // score rows: y0-1 .. y0+FT_H
+#ifdef EVH_FAST_TWO_LEVEL
+#define FSC_CAP (FT_W * FT_H / 2) // the A/B variant parks its first-level queue (<= 1020 quad indices) in the same words
+#else
+#define FSC_CAP 512              // scored-pixel list of the lifted path
+#endif
 
 // byte B (relative to the quad's own dword M; -4..-1 = left neighbour dword, 4..7 = right neighbour dword)
 template <int B>
@@ -490,7 +495,10 @@ struct FastLds {
   // its queue of quads with a pixel that passes the pre-test (<= 1020 entries, quad index | pass bits << 16): the
   // queue is dead before NMS writes the list.
   uint32_t lst[FS_H * FS_DW + 4];
-  uint16_t scored[FT_W * FT_H / 2];  // lifted path: pixels whose exact score reached T
+  // lifted path: pixels whose exact score reached T.  A few dozen per tile; a tile with more than FSC_CAP takes the
+  // full-plane NMS instead (fast_nms_collect), so the list can be short: 17.0 -> 14.5 KB of LDS per workgroup lets 11
+  // instead of 9 workgroups sit on a compute unit while some of them are down to their tail wave
+  uint16_t scored[FSC_CAP];
   alignas(16) uint32_t sink[4];      // target of the second staging store of threads that have no second item
   int lcnt, gbase, qcnt, scnt, q1cnt;
 };
@@ -761,7 +769,7 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
     if (s >= T) {
       scoreb[pos] = (uint8_t)s;
       const int k = atomicAdd(&S.scnt, 1);
-      if (k < FT_W * FT_H / 2) S.scored[k] = (uint16_t)pos;
+      if (k < FSC_CAP) S.scored[k] = (uint16_t)pos;
     }
   }
 }
@@ -771,7 +779,7 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
 __device__ __forceinline__ void fast_nms_scored(FastLds& S, const EvhLevel& L, int x0, int y0) {
   if (!((L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE))) return;
   const uint8_t* sc = reinterpret_cast<const uint8_t*>(S.score);
-  const int n = min(S.scnt, FT_W * FT_H / 2);
+  const int n = min(S.scnt, FSC_CAP);
   for (int i = threadIdx.x; i < n; i += 64) {
     const int pos = S.scored[i];
     const int sr = pos / FQ_PITCH, sx = pos - sr * FQ_PITCH;
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_sample(FastArgs A) {
   if (Tp) fast_lift_scores(S, L, x0, y0, Tp);          // exact scores >= Tp, zero elsewhere
   else fast_dense_scores(S, L, x0, y0);
   __syncthreads();
-  if (Tp && S.scnt <= FT_W * FT_H / 2) {               // workgroup-uniform: the short list of scored pixels is complete
+  if (Tp && S.scnt <= FSC_CAP) {               // workgroup-uniform: the short list of scored pixels is complete
     if (threadIdx.x < 64) fast_nms_scored(S, L, x0, y0);
   } else {
     fast_nms_collect(S, L, x0, y0);
@@ -970,7 +978,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_main(FastArgs A) {
   if (T > EVH_FAST_THR) {
     fast_lift_scores(S, L, x0, y0, T);
     __syncthreads();
-    if (S.scnt <= FT_W * FT_H / 2) {              // workgroup-uniform.  What is left is a few dozen scored pixels:
+    if (S.scnt <= FSC_CAP) {                      // workgroup-uniform.  What is left is a few dozen scored pixels:
       if (threadIdx.x >= 64) return;              // waves 1-3 are done (no barrier follows on this path), wave 0
       fast_nms_scored(S, L, x0, y0);              // runs NMS and the emission on its own
       fast_emit_wave0(S, A, L, f, l);
