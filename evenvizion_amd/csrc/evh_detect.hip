@@ -521,6 +521,7 @@ __device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const
   int rb = ra + 256 / C16, cb = ca + 256 % C16;
   if (cb >= C16) { cb -= C16; rb++; }
   const bool has_b = (int)threadIdx.x + 256 < NITEM;
+  if (!has_b) { rb = ra; cb = ca; }      // no second item: request the first one again (same line, no extra traffic)
   const uint4* img16 = reinterpret_cast<const uint4*>(img);
   // BOTH items are requested before either is stored (clamped addresses, unconditional loads: one memory round trip
   // per workgroup -- the predicated form compiled to load, wait, store, load, wait, store)
