@@ -142,6 +142,16 @@ if os.path.exists(b):
         tj = json.load(open(os.path.join(out, "traffic.json")))
         if rf.get("kernel") == "fast" and key in tj:
             rf["traffic"] = tj[key]["hbm_bytes"]
+            rf["traffic_over_algorithmic"] = round(rf["traffic"] / max(rf["algorithmic_bytes_per_launch"], 1), 3)
+            if "traffic_correction" in rf:
+                rf["traffic_correction"]["fetch_counter_bytes"] = tj[key]["fetch_counter_bytes"]
+                rf["traffic_correction"]["write_bytes"] = tj[key]["write_bytes"]
+            rf["traffic_source"] = "profiles/%s_pmc_hbm_traffic.csv: the PMC passes of the same collection run as this bench line (tools/collect_profiles.sh)" % tag
+        skey = "step@1280x720x1024_n500_c3"
+        if skey in tj and d.get("ms_per_step"):
+            gbs = tj[skey]["hbm_bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9
+            rf["hbm_traffic"] = {"bytes_per_step": tj[skey]["hbm_bytes_per_step"], "GBps": round(gbs, 1),
+                                 "frac_of_peak": round(gbs / 8000.0, 4), "source": tj[skey]["source"] + "; step time of this run"}
         vj = json.load(open(os.path.join(out, "valu.json"))).get(key)
         if vj and "valu_issue" in rf and rf.get("avg_launch_ms"):
             rf["valu_issue"]["wave_insts_per_launch"] = vj["valu_wave_insts_per_launch"]
