@@ -189,6 +189,5 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
     finally:
         if cuda:
             torch.cuda.synchronize(dev)                 # nothing of this call is left in flight on the shared buffers
-        runtime.release_staging()                       # nothing stays pinned / resident between videos
     homography_dict["resize_info"] = {"h": dh, "w": dw}
     return homography_dict

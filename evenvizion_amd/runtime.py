@@ -82,8 +82,8 @@ def _pin(t):
 
 def staging(shape, dev):
     """Two pinned host chunks, two device chunks, result buffers, a copy stream and events for the chunk pipeline of
-    get_homography_dict; cached per chunk shape while a video is being processed and dropped by release_staging()
-    (called at the end of get_homography_dict: nothing stays pinned or resident between videos)."""
+    get_homography_dict; cached per chunk shape (pinning hundreds of MB costs tens of milliseconds, a service processes many
+    videos of one size), each buffer capped at STAGING_BYTES_PER_BUFFER; release_staging() / reset() drop them."""
     import torch
     key = (tuple(shape), str(dev))
     if key not in _staging:
