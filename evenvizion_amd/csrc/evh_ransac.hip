@@ -929,6 +929,10 @@ __device__ __forceinline__ void lm_eval(SolveLds& S, int lane, const float* rows
   const int vi = lane - 36;                      // lanes 36..43: J^T r entry vi
   const int vx = vi < 3 ? vi : vi < 6 ? 3 : vi - 2, vy = vi < 3 ? 3 : vi < 6 ? vi - 3 : vi;
   double s = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, nrm = 0, rmax = 0;
+  // role of this lane in the sums: 1 = one J^T J entry (lanes 0..35), 2 = one J^T r entry (36..43), 3 = the squared norm (44)
+  const int role = withJ && lane < 36 ? 1 : withJ && lane < 44 ? 2 : lane == 44 ? 3 : 0;
+  const int pa = role == 1 ? jxi : role == 2 ? vx : 8, pb = role == 1 ? jxj : 8;
+  const int pc = role == 1 ? jyi : role == 2 ? vy : 9, pd = role == 1 ? jyj : 9;
   for (int c0 = 0; c0 < count; c0 += NL) {
     const int i = c0 + lane;
     if (i < count) {
@@ -950,39 +954,25 @@ __device__ __forceinline__ void lm_eval(SolveLds& S, int lane, const float* rows
     }
     WSYNC();
     const int cnt = min(NL, count - c0);
-    if (withJ && lane < 36) {
-#pragma unroll 4
-      for (int j = 0; j < cnt; j++) {
-        const double* t = T + j * TS;
-        s += t[jxi] * t[jxj];
-        s += t[jyi] * t[jyj];
-      }
-    } else if (withJ && lane < 44) {
+    // One instruction stream for the three kinds of sums (round 3; they were three divergent branches, i.e. three passes
+    // of the wave over the tile): every lane forms the same four products per PAIR of points from its own four term
+    // indices (pa, pb, pc, pd) -- J^T J entry: (jxi, jxj, jyi, jyj), J^T r entry: (vx, 8, vy, 9), squared norm: (8, 8, 9, 9)
+    // -- and only the additions differ: one running sum in point order / four interleaved partial sums / groups of four.
+    if (role) {
       int j = 0;
       for (; j + 1 < cnt; j += 2) {
         const double* t = T + j * TS;
-        s0 += t[vx] * t[8];
-        s1 += t[vy] * t[9];
-        s2 += t[TS + vx] * t[TS + 8];
-        s3 += t[TS + vy] * t[TS + 9];
+        const double P0 = t[pa] * t[pb], P1 = t[pc] * t[pd], P2 = t[TS + pa] * t[TS + pb], P3 = t[TS + pc] * t[TS + pd];
+        if (role == 1) { s += P0; s += P1; s += P2; s += P3; }
+        else if (role == 2) { s0 += P0; s1 += P1; s2 += P2; s3 += P3; }
+        else nrm += P0 + P1 + P2 + P3;
       }
       if (j < cnt) {                              // only at the very end (tiles hold an even number of points)
         const double* t = T + j * TS;
-        s0 += t[vx] * t[8];
-        s0 += t[vy] * t[9];
-      }
-    } else if (lane == 44) {
-      int j = 0;
-      for (; j + 1 < cnt; j += 2) {
-        const double* t = T + j * TS;
-        const double v0 = t[8], v1 = t[9], v2 = t[TS + 8], v3 = t[TS + 9];
-        nrm += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
-      }
-      if (j < cnt) {
-        const double* t = T + j * TS;
-        const double v0 = t[8], v1 = t[9];
-        nrm += v0 * v0;
-        nrm += v1 * v1;
+        const double P0 = t[pa] * t[pb], P1 = t[pc] * t[pd];
+        if (role == 1) { s += P0; s += P1; }
+        else if (role == 2) { s0 += P0; s0 += P1; }
+        else { nrm += P0; nrm += P1; }
       }
     }
     WSYNC();
