@@ -387,3 +387,24 @@ def test_detector_slot_overflow_is_a_pair_status_in_the_fused_path():
         assert got[1] == PAIR_CAPACITY and got[2] == PAIR_CAPACITY and got[0] == 0
     finally:
         c.close()
+
+
+def test_type_list_with_fused_resize_at_the_reference_geometry():
+    """The reference's example geometry: 1170x658 BGR frames, resize_width=400 -> 400x224 (video_processing.py:62,73), all
+    three detectors.  get_homography_dict on the full-size frames (imutils.resize fused into the ingest kernel) equals the
+    oracle's resize -> gray -> SURF + SIFT + ORB stream."""
+    from evenvizion_amd import runtime
+    from evenvizion_amd.processing import get_homography_dict
+    from evenvizion_amd.processing.video_processing import resized_shape
+    runtime.reset()
+    g, _ = S.make_stream(59, 4, 1170, 658)
+    full = np.stack([g, np.roll(g, 5, axis=2), 255 - g], axis=-1)          # three different channels
+    dw, dh = resized_shape(full.shape[1:], 400)
+    assert (dw, dh) == (400, 224)
+    gray = np.stack([O.bgr2gray(O.resize_area(f, dw, dh)) for f in full])
+    Hs, ss, rc = O.stream_gray_types(gray, ["SURF", "SIFT", "ORB"])
+    d = get_homography_dict(S.SyntheticCapture(list(full)), resize_width=400, chunk_frames=3)
+    got = np.array([d[k]["H"] for k in range(2, len(full) + 1)])
+    assert rc == -1 and (ss == 0).all() and d["resize_info"] == {"h": 224, "w": 400}
+    assert np.allclose(got, Hs, rtol=1e-9, atol=1e-12)
+    runtime.reset()

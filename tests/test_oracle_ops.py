@@ -185,3 +185,40 @@ def test_pair_and_stream_semantics():
     assert np.array_equal(Hs2[1], Hs2[0]) and np.array_equal(Hs2[2], Hs2[0])   # none_H_processing: previous H
     bad0 = frames.copy(); bad0[0] = 50
     assert O.stream_gray(bad0)[2] == 0                                   # failing FIRST pair: the reference raises
+
+
+def test_sift_and_surf_restatements_are_geometrically_sound():
+    """The SIFT / SURF halves of the oracle are restated from recall (parity unpinned).  What CAN be checked without the
+    operator: on a synthetic pair with a known H_true (cur pixel -> prev pixel) the ratio-test matches of each detector
+    reproject within a fraction of a pixel, key points come out in the operator's documented order, descriptors have the
+    documented norms, and the helper functions agree with their definitions."""
+    from evenvizion_amd import synthetic as S
+    prev, cur, Ht = S.make_pair(7, 400, 224)
+    for name, det in (("sift", O.sift_detect), ("surf", O.surf_detect)):
+        a, b = det(cur), det(prev)
+        assert len(a["xy"]) > 300 and len(b["xy"]) > 300
+        idx, dist = O.knn2_f32(a["desc"], b["desc"])
+        good = dist[:, 0] < 0.5 * dist[:, 1]
+        assert good.sum() > 100
+        pa = a["xy"][good].astype(np.float64); pb = b["xy"][idx[good, 0]].astype(np.float64)
+        pp = np.c_[pa, np.ones(len(pa))] @ Ht.T
+        err = np.linalg.norm(pp[:, :2] / pp[:, 2:] - pb, axis=1)
+        assert np.median(err) < 0.3 and (err < 1.5).mean() > 0.97, (name, np.median(err))
+    s = O.sift_detect(cur)
+    key = list(zip(s["xy"][:, 0].tolist(), s["xy"][:, 1].tolist()))
+    assert key == sorted(key)                                              # removeDuplicatedSorted: by x, then y
+    nrm = np.linalg.norm(s["desc"], axis=1)
+    assert np.all(s["desc"] == np.rint(s["desc"])) and s["desc"].max() <= 255 and abs(np.median(nrm) - 512) < 4
+    u = O.surf_detect(cur)
+    assert np.all(np.diff(u["response"]) <= 0) and u["response"].min() > 400   # KeypointGreater order, hessianThreshold
+    assert np.allclose(np.linalg.norm(u["desc"], axis=1), 1.0, atol=1e-5)
+    assert set(np.unique(u["laplacian"]).tolist()) <= {-1, 0, 1}
+    ii = O.integral(cur)
+    assert np.array_equal(ii[1:, 1:], cur.astype(np.int64).cumsum(0).cumsum(1)) and not ii[0].any() and not ii[:, 0].any()
+    lib = O.lib()
+    lib.evo_sift_exp32f.restype = lib.evo_sift_exp2.restype = __import__("ctypes").c_float
+    lib.evo_sift_exp32f.argtypes = lib.evo_sift_exp2.argtypes = [__import__("ctypes").c_float]
+    for x in (-30.0, -7.25, -1.0, -0.01, 0.0, 0.5, 3.0):
+        assert abs(lib.evo_sift_exp32f(x) - np.exp(np.float32(x))) <= 4e-7 * np.exp(x)       # hal::exp32f: ~1e-7 relative
+    for x in (0.0, 1 / 3, 0.5, 1.1666, -0.4):
+        assert lib.evo_sift_exp2(x) == np.float32(2.0 ** np.float64(np.float32(x)))          # 2^x rounded to float
