@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
   __shared__ float s_hist[160];
   __shared__ float s_dst[128];
   __shared__ float s_scale;
+  __shared__ int s_wtot[4];
   const int gf = blockIdx.y, f = f0 + gf, ki = blockIdx.x, tid = threadIdx.x;
   if (ki >= A.count[f]) return;
   const float* rec = A.kp + ((int64_t)f * A.cap + ki) * 8;
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
   for (int k0 = 0; k0 < total; k0 += 256) {
     const int k = k0 + tid;
     int base = -1;
+    float vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (k < total) {
       const int i = k / side - radius, j = k % side - radius;
       const float c_rot = (float)j * cos_t - (float)i * sin_t;
@@ -525,19 +527,31 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
         const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
         const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
         const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-        float* v = s_vals + tid * 8;
-        v[0] = v_rco000; v[1] = v_rco001; v[2] = v_rco010; v[3] = v_rco011;
-        v[4] = v_rco100; v[5] = v_rco101; v[6] = v_rco110; v[7] = v_rco111;
+        vv[0] = v_rco000; vv[1] = v_rco001; vv[2] = v_rco010; vv[3] = v_rco011;
+        vv[4] = v_rco100; vv[5] = v_rco101; vv[6] = v_rco110; vv[7] = v_rco111;
         base = ((r0 + 1) << 16) | ((c0 + 1) << 8) | o0;
       }
     }
-    s_base[tid] = base;
+    // the samples that contribute (about half of the window) are compacted IN ORDER before the bins walk them
+    const bool valid = base >= 0;
+    const unsigned long long vm = __ballot(valid);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) s_wtot[wv] = __popcll(vm);
+    __syncthreads();
+    int off = 0, nvalid = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int c = s_wtot[w]; if (w < wv) off += c; nvalid += c; }
+    if (valid) {
+      const int slot = off + __popcll(vm & ((1ull << lane) - 1ull));
+      s_base[slot] = base;
+      float* v = s_vals + slot * 8;
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = vv[q];
+    }
     __syncthreads();
     if (tid < 160) {
-      const int cnt = min(256, total - k0);
-      for (int s = 0; s < cnt; s++) {
+      for (int s = 0; s < nvalid; s++) {
         const int b = s_base[s];
-        if (b < 0) continue;
         const unsigned dr = (unsigned)(br - (b >> 16)), dc = (unsigned)(bc - ((b >> 8) & 255)), dq = (unsigned)(bo - (b & 255));
         if (dr < 2u && dc < 2u && dq < 2u) acc += s_vals[s * 8 + (int)(dr * 4 + dc * 2 + dq)];
       }
