@@ -1115,13 +1115,23 @@ struct BlockLds {
   unsigned long long red[NW];
 };
 
+// Hypotheses of one RANSAC call that were evaluated ahead of it by other workgroups (k_scan_hyp: the fixed-iteration
+// stream scan spreads the 2000 samples of a pair over ~140 workgroups; only the replay below is serial).
+struct ScanPre {
+  const int* hyp;                  // [count] valid << 31 | model << 30 | inlier count, in sample order
+  const double* H;                 // [count][9] the models
+  int count;                       // < 10000
+  unsigned long long rng_after;    // generator state after `count` quadruples
+};
+
 // ---- cv2.findHomography(a, b, RANSAC, thr) on `n` rows; result in B.s.H (LDS), mask[n] in global.  All NW*64
 // threads of the workgroup call this; the return value is uniform.  scratch: crow = float rows [n][4] for the
 // compacted inliers.  Ends with a workgroup barrier.
 template <int NW, bool LANES>
 __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, const float* rows, int n, double thr, int maxItersArg, double conf,
                                       int force_max, uint8_t* mask, float* crow, int* info, unsigned long long* prof,
-                                      double* lane_v /* LANES: this workgroup's NW * 81 * 64 doubles of global scratch */) {
+                                      double* lane_v /* LANES: this workgroup's NW * 81 * 64 doubles of global scratch */,
+                                      const ScanPre* pre = nullptr /* force_max only */) {
   const unsigned long long pf0 = pf_now();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15;
   SolveLds& S = B.s;
@@ -1147,6 +1157,38 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
   const FastMod fm((unsigned)n);
   int niters = max(maxItersArg, 1), maxGood = 0, iter = 0, run = 0, chunk = 0;
   bool stop = false;
+  if (pre) {
+    // Replay of the samples evaluated ahead, 64 at a time.  With the iteration count fixed the serial rule of the
+    // chunk loop below reduces to: the samples that count are the valid ones among the first `niters` valid ones, the
+    // winner is the FIRST of them with the largest inlier count (> 3); `run` = trailing rejected samples.
+    int lastvalid = -1;
+    unsigned long long bestkey = 0ull;
+    for (int c0 = 0; c0 < pre->count; c0 += NL) {
+      const int h = c0 + lane;
+      const unsigned e = h < pre->count ? (unsigned)pre->hyp[h] : 0u;
+      const bool v = (e >> 31) != 0u;
+      const unsigned long long vb = __ballot(v);
+      const int before = iter + __popcll(vb & ((1ull << lane) - 1ull));
+      if (v && before < niters && ((e >> 30) & 1u) && (e & 0x3FFFFFFFu) > 3u) {
+        const unsigned long long key = ((unsigned long long)(e & 0x3FFFFFFFu) << 32) | (0xFFFFFFFFu - (unsigned)h);
+        bestkey = key > bestkey ? key : bestkey;
+      }
+      if (__ballot(v && before >= niters) != 0ull) stop = true;
+      iter = min(iter + (int)__popcll(vb), niters);
+      if (vb) lastvalid = c0 + 63 - __clzll((long long)vb);
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const unsigned long long o = __shfl_xor(bestkey, sft);
+      bestkey = o > bestkey ? o : bestkey;
+    }
+    run = pre->count - 1 - lastvalid;
+    if (bestkey) {
+      maxGood = (int)(bestkey >> 32);
+      const int bh = (int)(0xFFFFFFFFu - (unsigned)bestkey);
+      if (tid < 9) S.bestH[tid] = pre->H[9 * (int64_t)bh + tid];
+    }
+    rng.state = pre->rng_after;
+  }
   while (!stop && iter < niters) {
     // every lane advances the generator identically through HC quadruples; the lanes of hypothesis h keep quadruple #h
     const unsigned long long pr0 = pf_now();
@@ -1371,7 +1413,8 @@ __device__ __forceinline__ int static_filter_block(BlockLds<NW, LANES>& B, const
 // All threads; uniform result; ends with a workgroup barrier.
 template <int NW, bool LANES>
 __device__ __forceinline__ int compute_homography_block(BlockLds<NW, LANES>& B, const float* rows, int n, const double* Hsup /*LDS|null*/,
-                                        const EvhRansacArgs& A, uint8_t* mask, float* trow, float* crow, int* info) {
+                                        const EvhRansacArgs& A, uint8_t* mask, float* trow, float* crow, int* info,
+                                        const ScanPre* pre = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* use = rows;
   if (Hsup) {
@@ -1387,7 +1430,7 @@ __device__ __forceinline__ int compute_homography_block(BlockLds<NW, LANES>& B, 
     __syncthreads();
     use = trow;
   }
-  const bool found = find_homography_block<NW, LANES>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof, A.lane_v ? A.lane_v + (int64_t)blockIdx.x * (NW * LV_ELEMS * NL) : nullptr);
+  const bool found = find_homography_block<NW, LANES>(B, use, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof, A.lane_v ? A.lane_v + (int64_t)blockIdx.x * (NW * LV_ELEMS * NL) : nullptr, pre);
   if (wave == 0) {
     int s = 0;
     for (int i = lane; i < n; i += NL) s += mask[i];
@@ -1469,6 +1512,38 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_pairs(EvhRansacArgs A)
   if (tid == 0) A.out_status[p] = st;
 }
 
+// the end of one step of the scan: status, H of the pair (a failed pair repeats the previous H, none_H_processing=True),
+// running superposition.  All threads; returns true when the scan stops here (uniform); ends with a workgroup barrier.
+template <int NW, bool LANES>
+__device__ __forceinline__ bool scan_step_tail(BlockLds<NW, LANES>& B, int st, int p, int npairs, double* Hout, int* stout, bool first) {
+  const int tid = threadIdx.x;
+  if (tid == 0) stout[p] = st;
+  if (st != EVH_PAIR_OK && !B.have_prev) {
+    // the reference raises here (None.tolist()); mark the pair and stop the scan
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    for (int q = p + 1 + tid; q < npairs; q += NW * NL) stout[q] = st;
+    for (int q = 9 * p + tid; q < 9 * npairs; q += NW * NL) Hout[q] = nan;
+    return true;
+  }
+  if (tid < 9) B.Hcur[tid] = st == EVH_PAIR_OK ? B.s.H[tid] : B.Hprev[tid];
+  __syncthreads();
+  if (tid < NL) {                          // wave 0
+    if (tid < 9) { Hout[9 * p + tid] = B.Hcur[tid]; B.Hprev[tid] = B.Hcur[tid]; }
+    // matrix_superposition (utils.py:139-145); np.dot(3x3,3x3) = forward FMA chain (pinned by fixtures)
+    double P = 0;
+    if (!first && tid < 9) {
+      const int r = tid / 3, c = tid - 3 * r;
+      P = fma(B.Hcur[3 * r + 2], B.Hsup[6 + c], fma(B.Hcur[3 * r + 1], B.Hsup[3 + c], B.Hcur[3 * r] * B.Hsup[c]));
+    }
+    const double P8 = __shfl(P, 8);
+    WSYNC();
+    if (tid < 9) B.Hsup[tid] = first ? B.Hcur[tid] : P / P8;
+    if (tid == 0) B.have_prev = 1;
+  }
+  __syncthreads();
+  return false;
+}
+
 // phase 2, stream semantics (video_processing.py:83-105): sequential scan over the pairs of one stream with the
 // running superposition; a failed pair repeats the previous H (none_H_processing=True).
 template <int NW, bool LANES>
@@ -1497,33 +1572,155 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A
                                         A.pts + slot0 * A.row_stride * 4, A.crow + slot0 * A.row_stride * 4,
                                         A.info ? A.info + 8 * (slot0 + p) + 4 : nullptr);
     }
-    if (tid == 0) stout[p] = st;
-    if (st != EVH_PAIR_OK && !B.have_prev) {
-      // the reference raises here (None.tolist()); mark the pair and stop the scan
-      const double nan = __longlong_as_double(0x7FF8000000000000ll);
-      for (int q = p + 1 + tid; q < npairs; q += NW * NL) stout[q] = st;
-      for (int q = 9 * p + tid; q < 9 * npairs; q += NW * NL) Hout[q] = nan;
-      return;
-    }
-    if (tid < 9) B.Hcur[tid] = st == EVH_PAIR_OK ? B.s.H[tid] : B.Hprev[tid];
-    __syncthreads();
-    if (tid < NL) {                          // wave 0
-      if (tid < 9) { Hout[9 * p + tid] = B.Hcur[tid]; B.Hprev[tid] = B.Hcur[tid]; }
-      // matrix_superposition (utils.py:139-145); np.dot(3x3,3x3) = forward FMA chain (pinned by fixtures)
-      double P = 0;
-      if (!first && tid < 9) {
-        const int r = tid / 3, c = tid - 3 * r;
-        P = fma(B.Hcur[3 * r + 2], B.Hsup[6 + c], fma(B.Hcur[3 * r + 1], B.Hsup[3 + c], B.Hcur[3 * r] * B.Hsup[c]));
-      }
-      const double P8 = __shfl(P, 8);
-      WSYNC();
-      if (tid < 9) B.Hsup[tid] = first ? B.Hcur[tid] : P / P8;
-      if (tid == 0) B.have_prev = 1;
-    }
+    if (scan_step_tail<NW, LANES>(B, st, p, npairs, Hout, stout, first)) return;
     first = false;
-    __syncthreads();
   }
   if (A.state_out && tid < 9) { A.state_out[18 * s + tid] = B.Hsup[tid]; A.state_out[18 * s + 9 + tid] = B.Hprev[tid]; }
+}
+
+// ---- fixed-iteration stream scan (force_max): the samples of a pair are independent, only the replay and the
+// refinement are serial, so every pair takes two launches: k_scan_hyp (one 16-hypothesis chunk per workgroup, ~140
+// workgroups) and k_scan_finish (one workgroup: replay, inlier mask, refit, LM, superposition).  The state of the scan
+// lives in global memory between the launches.
+struct ScanState { double Hsup[9], Hprev[9]; int have_prev, first, aborted, pad; };
+struct ScanWs {
+  ScanState* state;                // [nstreams]
+  unsigned long long* rng_after;   // [nstreams * npairs] generator state after the table of the pair
+  ushort4* quads;                  // [nstreams * npairs][hmax] the sample table: depends on the row count of the pair alone
+  int* hyp;                        // [nstreams][hmax]
+  double* hypH;                    // [nstreams][hmax][9]
+  int hmax;
+};
+
+__global__ __launch_bounds__(NL) void k_scan_init(EvhRansacArgs A, ScanWs W) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  ScanState& T = W.state[s];
+  if (tid < 9) { T.Hsup[tid] = A.Hsup0 ? A.Hsup0[18 * s + tid] : 0.0; T.Hprev[tid] = A.Hprev0 ? A.Hprev0[18 * s + tid] : 0.0; }
+  if (tid == 0) { T.have_prev = A.Hprev0 ? 1 : 0; T.first = A.Hsup0 ? 0 : 1; T.aborted = 0; T.pad = 0; }
+}
+
+// the sample quadruples of every pair of the batch, all pairs at once (getSubset: they depend on the row count only, so
+// they can be drawn before the scan reaches the pair)
+__global__ __launch_bounds__(NL) void k_scan_quads(EvhRansacArgs A, int npairs, int pitch, ScanWs W) {
+  const int b = blockIdx.x, s = b / npairs, p = b - s * npairs, lane = threadIdx.x;
+  const int64_t slot = (int64_t)s * pitch + p;
+  if (A.status[slot] != EVH_PAIR_OK) return;
+  const int n = A.npts2[slot];
+  if (n <= 4) return;
+  Rng rng;
+  const FastMod fm((unsigned)n);
+  ushort4* out = W.quads + (int64_t)b * W.hmax;
+  unsigned long long after = 0ull;
+  for (int h0 = 0; h0 < W.hmax; h0 += NL) {
+    int m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    for (int j = 0; j < NL; j++) {
+      const int q0 = (int)fm.mod(rng.next());
+      int q1, q2, q3;
+      do q1 = (int)fm.mod(rng.next()); while (q1 == q0);
+      do q2 = (int)fm.mod(rng.next()); while (q2 == q0 || q2 == q1);
+      do q3 = (int)fm.mod(rng.next()); while (q3 == q0 || q3 == q1 || q3 == q2);
+      if (j == lane) { m0 = q0; m1 = q1; m2 = q2; m3 = q3; }
+      if (h0 + j + 1 == W.hmax) after = rng.state;
+    }
+    if (h0 + lane < W.hmax) out[h0 + lane] = make_ushort4((unsigned short)m0, (unsigned short)m1, (unsigned short)m2, (unsigned short)m3);
+  }
+  if (lane == 0) W.rng_after[b] = after;
+}
+
+// one chunk of 16 hypotheses (a 16-lane row each) of pair p per workgroup; grid (hmax / 16, nstreams)
+__global__ __launch_bounds__(4 * NL) void k_scan_hyp(EvhRansacArgs A, int p, int npairs, int pitch, ScanWs W) {
+  BlockLds<4, false>& B = block_lds<4, false>();
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15, s = blockIdx.y;
+  const ScanState& T = W.state[s];
+  if (T.aborted) return;
+  const int64_t slot0 = (int64_t)s * pitch, slot = slot0 + p;
+  if (A.status[slot] != EVH_PAIR_OK) return;
+  const int n = A.npts2[slot];
+  if (n <= 4) return;
+  const float* use = A.pts2 + slot * A.row_stride * 4;
+  if (!T.first) {
+    // the rows in the fixed plane (compute_homography_block's transform).  Every workgroup of the pair writes the same
+    // values to the stream's one scratch slot and reads back what it wrote itself -- identical bits from every writer.
+    const float* rows = use;
+    float* trow = A.pts + slot0 * A.row_stride * 4;
+    if (tid < 9) B.Hsup[tid] = T.Hsup[tid];
+    __syncthreads();
+    for (int i = tid; i < n; i += 4 * NL) {
+      double tx, ty, tw;
+      hdot(B.Hsup, (double)rows[4 * i], (double)rows[4 * i + 1], &tx, &ty, &tw);
+      float ax = (float)(tx / tw), ay = (float)(ty / tw);
+      hdot(B.Hsup, (double)rows[4 * i + 2], (double)rows[4 * i + 3], &tx, &ty, &tw);
+      float bx = (float)(tx / tw), by = (float)(ty / tw);
+      *reinterpret_cast<float4*>(trow + 4 * i) = make_float4(ax, ay, bx, by);
+    }
+    __threadfence_block();
+    __syncthreads();
+    use = trow;
+  }
+  double thr = A.thr;
+  if (thr <= 0) thr = 3;
+  const float t = (float)(thr * thr);
+  const int hg = blockIdx.x * (4 * NG) + wave * NG + row;
+  const ushort4 q = W.quads[((int64_t)s * npairs + p) * W.hmax + hg];
+  const int my[4] = {q.x, q.y, q.z, q.w};
+  float Mx[4], My[4], mx[4], my_[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float4 r = *reinterpret_cast<const float4*>(use + 4 * my[i]);
+    Mx[i] = r.x; My[i] = r.y; mx[i] = r.z; my_[i] = r.w;
+  }
+  const bool valid = check_subset4(Mx, My, mx, my_);
+  double H[9];
+  const bool ok = dlt4_rows(B.m[wave][row], lane, valid, Mx, My, mx, my_, H);
+  int good = 0;
+  if (ok) {
+    float Hf[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+#pragma unroll 4
+    for (int i = gl; i < n; i += GL) {
+      const float4 r = *reinterpret_cast<const float4*>(use + 4 * i);
+      good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
+    }
+  }
+  good = rsum16(good);
+  if (gl == 0) {
+    W.hyp[(int64_t)s * W.hmax + hg] = (int)((valid ? 0x80000000u : 0u) | (ok ? 0x40000000u : 0u) | (unsigned)good);
+    double* Ho = W.hypH + ((int64_t)s * W.hmax + hg) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; i++) Ho[i] = ok ? H[i] : 0.0;
+  }
+}
+
+// the serial part of pair p: replay of the hypotheses, refinement, step of the scan; grid = nstreams
+__global__ __launch_bounds__(4 * NL) void k_scan_finish(EvhRansacArgs A, int p, int npairs, int pitch, ScanWs W) {
+  BlockLds<4, false>& B = block_lds<4, false>();
+  const int tid = threadIdx.x, s = blockIdx.x;
+  ScanState& T = W.state[s];
+  if (T.aborted) return;
+  const int64_t slot0 = (int64_t)s * pitch;
+  double* Hout = A.H + (int64_t)9 * s * npairs;
+  int* stout = A.out_status + (int64_t)s * npairs;
+  const bool first = T.first != 0;
+  if (tid == 0) B.have_prev = T.have_prev;
+  if (tid < 9) { B.Hsup[tid] = T.Hsup[tid]; B.Hprev[tid] = T.Hprev[tid]; }
+  __syncthreads();
+  int st = A.status[slot0 + p];
+  if (st == EVH_PAIR_OK) {
+    const int n = A.npts2[slot0 + p];
+    const float* rows = A.pts2 + (slot0 + p) * A.row_stride * 4;
+    const ScanPre pre{W.hyp + (int64_t)s * W.hmax, W.hypH + (int64_t)s * W.hmax * 9, W.hmax, n > 4 ? W.rng_after[(int64_t)s * npairs + p] : 0ull};
+    st = compute_homography_block<4, false>(B, rows, n, first ? nullptr : B.Hsup, A, A.mask + slot0 * A.row_stride,
+                                            A.pts + slot0 * A.row_stride * 4, A.crow + slot0 * A.row_stride * 4,
+                                            A.info ? A.info + 8 * (slot0 + p) + 4 : nullptr, n > 4 ? &pre : nullptr);
+  }
+  if (scan_step_tail<4, false>(B, st, p, npairs, Hout, stout, first)) {
+    if (tid == 0) T.aborted = 1;
+    return;
+  }
+  if (tid < 9) { T.Hsup[tid] = B.Hsup[tid]; T.Hprev[tid] = B.Hprev[tid]; }
+  if (tid == 0) { T.have_prev = 1; T.first = 0; }
+  if (p == npairs - 1 && A.state_out && tid < 9) { A.state_out[18 * s + tid] = B.Hsup[tid]; A.state_out[18 * s + 9 + tid] = B.Hprev[tid]; }
 }
 
 // waves per workgroup: enough rows to cover the handful of hypotheses an adaptive RANSAC needs in one chunk when the
@@ -1532,6 +1729,45 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A
 int waves_for(int nblocks, int force_max) {
   if (force_max) return 0;      // the LANES form
   return nblocks >= 512 ? 1 : 4;
+}
+
+// workspace of the fixed-iteration stream scan, grown on demand
+int scan_ws(evh_ctx* c, int nstreams, int npairs, int hmax, ScanWs* W) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t slots = (size_t)nstreams * npairs;
+  const size_t o_state = 0, o_rng = o_state + up(sizeof(ScanState) * nstreams), o_quads = o_rng + up(8 * slots),
+               o_hyp = o_quads + up(sizeof(ushort4) * slots * hmax), o_H = o_hyp + up(sizeof(int) * (size_t)nstreams * hmax),
+               total = o_H + up(sizeof(double) * 9 * (size_t)nstreams * hmax);
+  if (c->scan_ws_bytes < total) {
+    if (c->d_scan_ws) { EVH_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_scan_ws); c->d_scan_ws = nullptr; c->scan_ws_bytes = 0; }
+    EVH_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_scan_ws), total));
+    c->scan_ws_bytes = total;
+  }
+  char* b = c->d_scan_ws;
+  W->state = reinterpret_cast<ScanState*>(b + o_state); W->rng_after = reinterpret_cast<unsigned long long*>(b + o_rng);
+  W->quads = reinterpret_cast<ushort4*>(b + o_quads); W->hyp = reinterpret_cast<int*>(b + o_hyp);
+  W->hypH = reinterpret_cast<double*>(b + o_H); W->hmax = hmax;
+  return EVH_SUCCESS;
+}
+
+int launch_forced_scan(evh_ctx* c, const EvhRansacArgs& A, int npairs, int nstreams, int pitch) {
+  if (A.row_stride > 65536) return evh_fail(c, EVH_ERR_INVALID, "fixed-iteration scan: more than 65536 rows per pair");
+  // enough chunks for max_iters counted samples plus 1/8 of rejected ones; a pair that needs more continues inside
+  // k_scan_finish with the ordinary chunk loop
+  const int iters = A.max_iters > 0 ? A.max_iters : 1;
+  int chunks = (iters + iters / 8 + 4 * NG - 1) / (4 * NG) + 1;
+  if (const char* e = getenv("EVH_SCAN_CHUNKS")) chunks = atoi(e) > 0 ? atoi(e) : chunks;   // tests: a short table, the rest in k_scan_finish
+  if (chunks > 608) chunks = 608;                                   // < 10000 samples (ScanPre)
+  ScanWs W;
+  int rc = scan_ws(c, nstreams, npairs, chunks * 4 * NG, &W);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scan_init, dim3(nstreams), dim3(NL), 0, c->stream, A, W);
+  hipLaunchKernelGGL(k_scan_quads, dim3(nstreams * npairs), dim3(NL), 0, c->stream, A, npairs, pitch, W);
+  for (int p = 0; p < npairs; p++) {
+    hipLaunchKernelGGL(k_scan_hyp, dim3(chunks, nstreams), dim3(4 * NL), 0, c->stream, A, p, npairs, pitch, W);
+    hipLaunchKernelGGL(k_scan_finish, dim3(nstreams), dim3(4 * NL), 0, c->stream, A, p, npairs, pitch, W);
+  }
+  return EVH_SUCCESS;
 }
 
 }  // namespace
@@ -1577,7 +1813,10 @@ int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A_, int npairs, int
     A.prof = d_prof;
   }
   // nstreams == 0: independent pairs; otherwise nstreams sequential scans of npairs pairs each, `pitch` pair slots apart
-  if (nstreams > 0) EVH_LAUNCH_NW(waves_for(nstreams, A.force_max), k_ransac_final_stream, nstreams, c->stream, A, npairs, pitch);
+  if (nstreams > 0 && A.force_max && !getenv("EVH_SCAN_ONE_WG")) {
+    const int fr = launch_forced_scan(c, A, npairs, nstreams, pitch);
+    if (fr) { if (d_prof) (void)hipFree(d_prof); return fr; }
+  } else if (nstreams > 0) EVH_LAUNCH_NW(waves_for(nstreams, A.force_max), k_ransac_final_stream, nstreams, c->stream, A, npairs, pitch);
   else EVH_LAUNCH_NW(waves_for(npairs, A.force_max), k_ransac_final_pairs, npairs, c->stream, A);
   {
     const hipError_t le = hipGetLastError();

@@ -639,6 +639,45 @@ def test_fixed_iterations_in_every_batch_form():
         c.close()
 
 
+def test_fixed_iteration_scan_forms(monkeypatch):
+    """The fixed-iteration stream scan spreads the samples of a pair over many workgroups (k_scan_hyp + k_scan_finish,
+    VERDICT r2 item 6a).  Every form must give the oracle's stream: the default table (all samples ahead), a short
+    table (EVH_SCAN_CHUNKS=3: 48 samples ahead, the rest in the chunk loop of k_scan_finish) and the single-workgroup
+    kernel (EVH_SCAN_ONE_WG=1); with a failing pair mid-stream (H repeats, state carried between the launches), state
+    carried across two calls, and a failing first pair (NaN + stop)."""
+    from evenvizion_amd._lib import Context
+    w, h = 400, 224
+    fr, _ = S.make_stream(9, 7, w, h)
+    flat = np.full((h, w), 128, np.uint8)
+    s1 = np.stack([fr[0], fr[1], flat, fr[2], fr[3], fr[4], fr[5]])
+    s2 = np.stack([flat, fr[1], fr[2], fr[3]])
+    Ho1, so1, rc1 = O.stream_gray(s1, force_max_iters=True)
+    _, so2, rc2 = O.stream_gray(s2, force_max_iters=True)
+    assert rc1 == -1 and list(so1) == [0, 1, 1, 0, 0, 0] and rc2 == 0
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=8)
+    try:
+        for env in ({}, {"EVH_SCAN_CHUNKS": "3"}, {"EVH_SCAN_ONE_WG": "1"}):
+            monkeypatch.delenv("EVH_SCAN_CHUNKS", raising=False); monkeypatch.delenv("EVH_SCAN_ONE_WG", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            H1 = torch.zeros(6, 9, dtype=torch.float64, device="cuda"); st1 = torch.full((6,), -1, dtype=torch.int32, device="cuda")
+            c.stream_homography_batch(dev(s1), H1, st1, force_max_iters=True); c.synchronize()
+            assert np.array_equal(st1.cpu().numpy(), so1), env
+            assert np.allclose(H1.cpu().numpy().reshape(-1, 3, 3), Ho1, rtol=1e-9, atol=1e-12), env
+            # the same stream in two calls with the state handed over
+            state = torch.zeros(18, dtype=torch.float64, device="cuda")
+            Ha = torch.zeros(3, 9, dtype=torch.float64, device="cuda"); sa = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+            Hb = torch.zeros(3, 9, dtype=torch.float64, device="cuda"); sb = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+            c.stream_homography_batch(dev(s1[:4]), Ha, sa, state_out=state, force_max_iters=True)
+            c.stream_homography_batch(dev(s1[3:]), Hb, sb, state_in=state, state_out=state, force_max_iters=True); c.synchronize()
+            assert torch.equal(torch.cat([Ha, Hb]), H1) and torch.equal(torch.cat([sa, sb]), st1), env
+            H2 = torch.zeros(3, 9, dtype=torch.float64, device="cuda"); st2 = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+            c.stream_homography_batch(dev(s2), H2, st2, force_max_iters=True); c.synchronize()
+            assert st2.cpu().tolist() == [1, 1, 1] and bool(torch.isnan(H2).all()), env
+    finally:
+        c.close()
+
+
 def test_resize_area(ctx):
     rng = np.random.default_rng(4)
     for (sw, sh, width, cn) in [(1170, 658, 400, 3), (1280, 720, 320, 3), (800, 600, 400, 1), (900, 300, 300, 3),
