@@ -386,6 +386,132 @@ __global__ __launch_bounds__(256) void k_gray_pyr1(const uint8_t* __restrict__ s
   }
 }
 
+// K2, two levels per launch (round 3): a workgroup owns one 128 x 32 tile of level l+1.  It stages the
+// level l-1 footprint of the level-l pixels that tile needs, produces those level-l pixels into LDS, stores the ones it
+// OWNS (the partition of k_gray_pyr1: columns [xofs[x0] & ~3, xofs[x0 + 128] & ~3), rows [yofs[y0], yofs[y0 + 32]) of the
+// level l+1 tap tables) and then produces its level l+1 tile from LDS: level l is written once and never read back
+// (levels 2..7 in three launches; HBM bytes per frame 3.15 -> 2.39 MB at 720p).  Same arithmetic as k_pyr_down.
+#define P2_SW 240    // staged level l-1 row bytes (>= 1.21*176 + 2 + 15, multiple of 16)
+#define P2_SH 57     // staged level l-1 rows      (>= 1.21*44 + 3)
+struct Pyr2Level { int64_t off; int stride, w, h; const int *xofs, *xc1, *yofs, *yc1; };
+__global__ __launch_bounds__(256) void k_pyr_two(uint8_t* __restrict__ pyr, int64_t pyr_frame_bytes, int64_t s_off,
+                                                 int s_stride, Pyr2Level M, Pyr2Level D, int tiles_x, int tiles_y,
+                                                 int tx_magic, int nframes) {
+  __shared__ uint32_t tileS[P2_SH * P2_SW / 4];
+  __shared__ uint32_t tileM[GP_SH * GP_SW / 4];
+  __shared__ int x1o[GP_SW]; __shared__ int x1c[GP_SW]; __shared__ int y1o[GP_SH]; __shared__ int y1c[GP_SH];
+  __shared__ int xo_s[PD_W]; __shared__ int xc_s[PD_W]; __shared__ int yo_s[PD_H]; __shared__ int yc_s[PD_H];
+  int f, bt;
+  xcd_order(bt, f);
+  if (bt >= tiles_x * tiles_y || f >= nframes) return;  // grid padding (workgroup-uniform)
+  const int ty = div_magic20(bt, tx_magic), tx = bt - ty * tiles_x;
+  const int x0 = tx * PD_W, y0 = ty * PD_H;
+  const int x1 = min(x0 + PD_W, D.w) - 1, y1 = min(y0 + PD_H, D.h) - 1;
+  // level-l region of this workgroup: what it owns and what its level l+1 tile reads
+  const int rx0 = D.xofs[x0] & ~3, ry0 = D.yofs[y0];
+  const int own_x1 = (tx == tiles_x - 1) ? ((M.w + 3) & ~3) : (D.xofs[x0 + PD_W] & ~3);
+  const int own_y1 = (ty == tiles_y - 1) ? M.h : D.yofs[y0 + PD_H];
+  const int rx1 = max(own_x1, min(D.xofs[x1] + 2, M.w)), ry1 = max(own_y1, min(D.yofs[y1] + 2, M.h));   // exclusive
+  const int nqx = (rx1 - rx0 + 3) >> 2, nr = ry1 - ry0;                                                 // <= 44, <= 44
+  // level l-1 footprint of that region (a right / bottom edge tap is (size - 2, weight 256): ofs + 1 stays inside)
+  const int cx1 = min(rx1, M.w) - 1;
+  const int sx0 = M.xofs[rx0] & ~15, sy0 = M.yofs[ry0];
+  const int ex = M.xofs[cx1] + 1, ey = M.yofs[ry1 - 1] + 1;
+  const int ncol16 = (ex - sx0) / 16 + 1, nrow = ey - sy0 + 1;     // <= P2_SW/16 = 15, <= P2_SH
+  uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;
+  {
+    // 16 threads per staged row (<= 15 move a 16-byte cell); a thread's four cells (rows 16 apart) are all requested
+    // before the first is stored: clamped addresses, the stores carry the bounds
+    const int c16 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    const uint4* colc = reinterpret_cast<const uint4*>(base + s_off + sx0) + min(c16, ncol16 - 1);
+    const int stride16 = s_stride >> 4;
+    static_assert((P2_SH + 15) / 16 == 4, "four staged rows per thread");
+#define P2_LD(k) colc[mad24((uint32_t)(sy0 + min(r0 + 16 * (k), nrow - 1)), (uint32_t)stride16, 0u)]
+    const uint4 v0 = P2_LD(0), v1 = P2_LD(1), v2 = P2_LD(2), v3 = P2_LD(3);
+#undef P2_LD
+    // the tap tables of both levels while the loads are in flight
+    for (int t = threadIdx.x; t < GP_SW + GP_SH + PD_W + PD_H; t += 256) {
+      if (t < GP_SW) {
+        const int xi = min(rx0 + t, M.w - 1);
+        x1o[t] = M.xofs[xi] - sx0; x1c[t] = M.xc1[xi];
+      } else if (t < GP_SW + GP_SH) {
+        const int r = t - GP_SW, yi = min(ry0 + r, M.h - 1);
+        y1o[r] = M.yofs[yi] - sy0; y1c[r] = M.yc1[yi];
+      } else if (t < GP_SW + GP_SH + PD_W) {
+        const int c = t - GP_SW - GP_SH, xi = min(x0 + c, D.w - 1);
+        xo_s[c] = D.xofs[xi] - rx0; xc_s[c] = D.xc1[xi];
+      } else {
+        const int r = t - GP_SW - GP_SH - PD_W, yi = min(y0 + r, D.h - 1);
+        yo_s[r] = D.yofs[yi] - ry0; yc_s[r] = D.yc1[yi];
+      }
+    }
+    if (c16 < ncol16) {
+      uint4* d = reinterpret_cast<uint4*>(&tileS[r0 * (P2_SW / 4) + c16 * 4]);
+      if (r0 < nrow) d[0] = v0;
+      if (r0 + 16 < nrow) d[16 * (P2_SW / 16)] = v1;
+      if (r0 + 32 < nrow) d[32 * (P2_SW / 16)] = v2;
+      if (r0 + 48 < nrow) d[48 * (P2_SW / 16)] = v3;
+    }
+  }
+  __syncthreads();
+  {
+    // level l: every quad of the region from the staged level l-1 bytes; owned quads also go to HBM
+    const uint8_t* ts = reinterpret_cast<const uint8_t*>(tileS);
+    uint8_t* mimg = base + M.off;
+    const float inv = 1.0f / (float)nqx;
+    for (int q = threadIdx.x; q < nqx * nr; q += 256) {
+      const int r = (int)(((float)q + 0.5f) * inv);     // exact: q + 0.5 is at least 0.5 away from a multiple of nqx
+      const int qx = q - (int)mad24((uint32_t)r, (uint32_t)nqx, 0u);
+      const int x = rx0 + 4 * qx, y = ry0 + r;
+      if (x >= M.w) continue;                            // padding quad: never read by a tap, never stored
+      const uint8_t* r0p = ts + y1o[r] * P2_SW;
+      const uint8_t* r1p = r0p + P2_SW;
+      const uint32_t m1 = (uint32_t)y1c[r], m0 = 256u - m1;
+      uint32_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int o = x1o[qx * 4 + i];
+        const uint32_t c1 = (uint32_t)x1c[qx * 4 + i], c0 = 256u - c1;
+        const uint32_t a0 = r0p[o], b0 = r0p[o + 1], a1 = r1p[o], b1 = r1p[o + 1];
+        const uint32_t h0 = mad24(a0, c0, mad24(b0, c1, 0u));
+        const uint32_t h1 = mad24(a1, c0, mad24(b1, c1, 0u));
+        v[i] = mad24(h0, m0, mad24(h1, m1, 32768u));
+      }
+      const uint32_t out = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020C0Cu);
+      tileM[r * (GP_SW / 4) + qx] = out;
+      if (x < own_x1 && y < own_y1)
+        *reinterpret_cast<uint32_t*>(mimg + mad24((uint32_t)y, (uint32_t)M.stride, (uint32_t)x)) = out;
+    }
+  }
+  __syncthreads();
+  uint8_t* dimg = base + D.off;
+  const uint8_t* tile = reinterpret_cast<const uint8_t*>(tileM);
+  const int qx = threadIdx.x & 31, qy = threadIdx.x >> 5;
+  const int x = x0 + qx * 4;
+  if (x >= D.w) return;
+#pragma unroll
+  for (int rr = 0; rr < PD_H / 8; rr++) {
+    const int y = y0 + qy * (PD_H / 8) + rr;
+    if (y >= D.h) break;
+    const uint8_t* r0 = tile + yo_s[qy * (PD_H / 8) + rr] * GP_SW;
+    const uint8_t* r1 = r0 + GP_SW;
+    const int m1 = yc_s[qy * (PD_H / 8) + rr];
+    const uint32_t m0 = 256u - (uint32_t)m1;      // same arithmetic as k_pyr_down
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int o = xo_s[qx * 4 + i];
+      const uint32_t c1 = (uint32_t)xc_s[qx * 4 + i], c0 = 256u - c1;
+      const uint32_t a0 = r0[o], b0 = r0[o + 1], a1 = r1[o], b1 = r1[o + 1];
+      const uint32_t h0 = mad24(a0, c0, mad24(b0, c1, 0u));
+      const uint32_t h1 = mad24(a1, c0, mad24(b1, c1, 0u));
+      v[i] = mad24(h0, m0, mad24(h1, (uint32_t)m1, 32768u));
+    }
+    const uint32_t out = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020C0Cu);
+    reinterpret_cast<uint32_t*>(dimg)[mad24((uint32_t)y, (uint32_t)(D.stride >> 2), (uint32_t)(x >> 2))] = out;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K3: FAST-9/16 + corner score + 3x3 NMS + 31-px border filter, all pyramid levels of all frames in one launch.
 // Workgroup = 64x32 output tile; the tile plus a 4-pixel halo is staged in LDS (coalesced dword loads), the
@@ -1503,14 +1629,33 @@ int evh_launch_gray_level0(evh_ctx* c, const uint8_t* d_frames, int nframes, int
 }
 
 int evh_launch_pyramid(evh_ctx* c, int nframes) {
-  static const bool old_form = getenv("EVH_PYR_OLD") != nullptr;     // A/B aid: the round-2 kernel (k_pyr_down, 128 x 64 tiles)
+  // A/B aids, read at every launch (tests switch them): the round-2 kernel (k_pyr_down, 128 x 64 tiles) and two levels per
+  // launch (k_pyr_two: 24 % fewer HBM bytes, 70 % slower -- the pyramid is bound by its LDS byte reads and multiply-adds,
+  // profiles/r03_pyramid_two_ab.txt)
+  const bool old_form = getenv("EVH_PYR_OLD") != nullptr;
+  const bool two_form = getenv("EVH_PYR_TWO") != nullptr;
+  auto shrink_ok = [](const EvhLevel& S, const EvhLevel& D) {          // <= 1.21 x per axis: what the staged footprints are sized for
+    return (int64_t)S.w * 100 <= (int64_t)D.w * 121 && (int64_t)S.h * 100 <= (int64_t)D.h * 121 && D.w >= 2 && D.h >= 2;
+  };
   for (int l = c->level1_fused ? 2 : 1; l < EVH_NLEVELS; l++) {
     const EvhLevel& S = c->g.lv[l - 1];
     const EvhLevel& D = c->g.lv[l];
     const int* t = c->d_tabs + D.tab_off;   // xofs | xc1 | yofs | yc1 (linear_exact_tab in evh_api.hip)
+    if (two_form && l + 1 < EVH_NLEVELS && shrink_ok(S, D) && shrink_ok(D, c->g.lv[l + 1])) {
+      const EvhLevel& E = c->g.lv[l + 1];
+      const int* t2 = c->d_tabs + E.tab_off;
+      const Pyr2Level PM{D.off, D.stride, D.w, D.h, t, t + D.w, t + 2 * D.w, t + 2 * D.w + D.h};
+      const Pyr2Level PD{E.off, E.stride, E.w, E.h, t2, t2 + E.w, t2 + 2 * E.w, t2 + 2 * E.w + E.h};
+      const int tiles_x = (E.w + PD_W - 1) / PD_W, tiles_y = (E.h + PD_H - 1) / PD_H;
+      hipLaunchKernelGGL(k_pyr_two, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,
+                         c->g.pyr_frame_bytes, S.off, S.stride, PM, PD, tiles_x, tiles_y, magic20(tiles_x), nframes);
+      EVH_HIP(c, hipGetLastError());
+      l++;
+      continue;
+    }
     // the row-walking kernel stages <= 1.21 x its tile: ORB's levels shrink by 1.2 (a first level built from a
     // resized frame never comes here: level 0 -> 1 has the same ratio)
-    const bool walk = !old_form && (int64_t)S.w * 100 <= (int64_t)D.w * 121 && (int64_t)S.h * 100 <= (int64_t)D.h * 121;
+    const bool walk = !old_form && shrink_ok(S, D);
     if (walk) {
       const int tiles_x = (D.w + PW_W - 1) / PW_W, tiles_y = (D.h + PW_H - 1) / PW_H;
       hipLaunchKernelGGL(k_pyr_walk, xcd_grid(tiles_x * tiles_y, nframes), dim3(256), 0, c->stream, c->d_pyr,

@@ -60,6 +60,27 @@ def test_pyramid_and_gray(ctx, w, h):
             assert np.array_equal(got, want[l]), "level %d differs" % l
 
 
+@pytest.mark.parametrize("form", ["EVH_PYR_OLD", "EVH_PYR_TWO"])
+def test_pyramid_alternative_kernels(ctx, monkeypatch, form):
+    """The two other pyramid kernels kept for A/B runs (k_pyr_down: round 2's tiles; k_pyr_two: levels l and l+1 from one
+    staged footprint of level l-1, VERDICT r2 item 5 -- measured slower, profiles/r03_pyramid_two_ab.txt) produce the
+    same bytes as the oracle (frame_processing.py:60-61)."""
+    monkeypatch.setenv(form, "1")
+    for (w, h) in SIZES + [(1170, 658), (641, 363)]:
+        prev, cur, _ = S.make_pair(7, w, h)
+        from evenvizion_amd._lib import Context
+        c = ctx if (w, h) in SIZES else Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=2)
+        try:
+            c.orb_detect_batch(dev(np.stack([prev, cur])))
+            for f, img in enumerate((prev, cur)):
+                want = O.orb_pyramid(img)
+                for l in range(8):
+                    assert np.array_equal(c.download_level(f, l), want[l]), "%s %dx%d level %d differs" % (form, w, h, l)
+        finally:
+            if c is not ctx:
+                c.close()
+
+
 @pytest.mark.parametrize("w,h", SIZES)
 def test_fast_candidates(ctx, w, h):
     prev, cur, _ = S.make_pair(11, w, h)
