@@ -128,23 +128,28 @@ __global__ __launch_bounds__(64) void k_knn2_f32(EvhKnnF32Args A) {
   if ((int)blockIdx.x * 64 >= nq) return;
   const int qi = blockIdx.x * 64 + threadIdx.x;
   const bool act = qi < nq;
-  float q[DIM];
+  // two-element vectors: the compiler emits v_pk_add_f32 / v_pk_mul_f32 (two IEEE f32 operations per lane and issue slot,
+  // no contraction); the pairs are neighbouring elements, so every one of the eight running sums still sees exactly
+  // the operator's sequence of operations
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f q[DIM / 2];
   const float4* Q = reinterpret_cast<const float4*>(Qb + (int64_t)(act ? qi : 0) * DIM);
 #pragma unroll
-  for (int k = 0; k < DIM / 4; k++) { const float4 v = Q[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
+  for (int k = 0; k < DIM / 4; k++) { const float4 v = Q[k]; q[2 * k] = v2f{v.x, v.y}; q[2 * k + 1] = v2f{v.z, v.w}; }
   float b0 = FLT_MAX, b1 = FLT_MAX;
   int i0 = -1, i1 = -1;
   for (int j = 0; j < nt; j++) {
-    const float* t = Tb + (int64_t)j * DIM;
-    float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f};
+    const v2f* t = reinterpret_cast<const v2f*>(Tb + (int64_t)j * DIM);
+    v2f d0a = {0.f, 0.f}, d0b = {0.f, 0.f}, d1a = {0.f, 0.f}, d1b = {0.f, 0.f};   // d0[0..1], d0[2..3], d1[0..1], d1[2..3]
 #pragma unroll
-    for (int k = 0; k < DIM; k += 8)
-#pragma unroll
-      for (int l = 0; l < 4; l++) {
-        const float t0 = q[k + l] - t[k + l], t1 = q[k + 4 + l] - t[k + 4 + l];
-        d0[l] = d0[l] + t0 * t0;
-        d1[l] = d1[l] + t1 * t1;
-      }
+    for (int k = 0; k < DIM / 2; k += 4) {
+      const v2f e0 = q[k] - t[k], e1 = q[k + 1] - t[k + 1], e2 = q[k + 2] - t[k + 2], e3 = q[k + 3] - t[k + 3];
+      d0a = d0a + e0 * e0;
+      d0b = d0b + e1 * e1;
+      d1a = d1a + e2 * e2;
+      d1b = d1b + e3 * e3;
+    }
+    const float d0[4] = {d0a.x, d0a.y, d0b.x, d0b.y}, d1[4] = {d1a.x, d1a.y, d1b.x, d1b.y};
     const float u0 = d0[0] + d1[0], u1 = d0[1] + d1[1], u2 = d0[2] + d1[2], u3 = d0[3] + d1[3];
     const float ds = sqrtf(u0 + u1 + u2 + u3);
     if (ds < b1) {

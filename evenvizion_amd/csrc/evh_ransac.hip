@@ -762,10 +762,13 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // optional in-kernel cycle accounting (EVH_RANSAC_PROF=1): slots of A.prof, accumulated by thread 0
 enum { PF_CALLS = 0, PF_HYP, PF_CHUNKS, PF_COMPACT, PF_REFIT, PF_LM, PF_LM_ITERS, PF_SOLVE8, PF_EVAL, PF_TOTAL, PF_ROT9,
-       PF_ROT8, PF_SETUP, PF_RNG, PF_COUNT, PF_BARRIER, PF_REPLAY, PF_NSLOTS };
+       PF_ROT8, PF_SETUP, PF_RNG, PF_COUNT, PF_BARRIER, PF_REPLAY, PF_MW_W0, PF_MW_W1T, PF_MW_PROD, PF_MW_STEPS, PF_NSLOTS };
 __device__ __forceinline__ unsigned long long pf_now() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ void pf_add(unsigned long long* prof, int slot, unsigned long long v) {
   if (prof && threadIdx.x == 0) atomicAdd(prof + slot, v);
+}
+__device__ __forceinline__ void pf_add_wave(unsigned long long* prof, int slot, unsigned long long v) {   // lane 0 of any wave
+  if (prof && (threadIdx.x & 63) == 0) atomicAdd(prof + slot, v);
 }
 
 struct SolveLds {        // scratch of the single-problem stages (refit, LM): used by wave 0 only
@@ -1009,14 +1012,17 @@ __device__ __forceinline__ double dot8(const double* a, const double* b) {
 
 // Levenberg-Marquardt refinement of S.H[0..7] over `count` rows (<= 10 iterations). Returns iterations.  Wave 0.
 // S.sc: 0 = S, 1 = rmax of the kept point, 2 = lambda, 3 = lc, 4 = nu, 5 = Sd, 6 = rmax of the trial point
+// evalJ(): the pass WITH the Jacobian at S.x into S.sc[0], S.sc[1], S.A8, S.v -- lm_eval by this wave alone, or the
+// four-wave form (lm_eval_mw) where the workgroup has helper waves.
+template <typename EvalJ>
 __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const float* rows, int count,
-                                         unsigned long long* prof = nullptr) {
+                                         unsigned long long* prof, EvalJ evalJ) {
   const int maxIters = 10;
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   if (lane < 8) S.x[lane] = S.H[lane];
   WSYNC();
   unsigned long long pe = pf_now();
-  lm_eval(S, lane, rows, count, S.x, true, 0, 1);
+  evalJ();
   pf_add(prof, PF_EVAL, pf_now() - pe);
   if (lane < 8) S.D[lane] = S.A8[lane * 8 + lane];
   if (lane == 0) { S.sc[2] = 1; S.sc[3] = 0.75; }  // lambda, lc
@@ -1082,7 +1088,7 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
       if (lane < 8) { const double t = S.x[lane]; S.x[lane] = S.xd[lane]; S.xd[lane] = t; }
       WSYNC();
       pe = pf_now();
-      lm_eval(S, lane, rows, count, S.x, true, 0, 1);   // residuals / Jacobian at the accepted point (S = Sd again)
+      evalJ();                                          // residuals / Jacobian at the accepted point (S = Sd again)
       pf_add(prof, PF_EVAL, pf_now() - pe);
     }
     iter++;
@@ -1114,6 +1120,183 @@ struct BlockLds {
   } u;
   unsigned long long red[NW];
 };
+
+// ---- lm_eval with the Jacobian, all four waves of the workgroup (round 3).  The sums of J^T J and J^T r are strictly
+// sequential over the points (the operator's order), but only their ADDITIONS are: the products are formed ahead by
+// other waves.  Steps of 16 points, one workgroup barrier per step, everything double-buffered:
+//   wave 1     terms of the next 64-point tile (every fourth step; its rows are requested one step ahead), max |r| and
+//              the pair sums of the squared residuals of that tile
+//   wave 2 / 3 the x- / y-row products of the 44 entries (lane = entry) for the 16 points of the NEXT step: all lanes
+//              read the same point's terms (10 words: no bank conflict) and write the product buffer of that step as [point][x|y][entry]
+//   wave 0     the additions of THIS step (lane = entry: 36 J^T J entries, one running sum in point order; 8 J^T r
+//              entries, four interleaved partial sums) and, every fourth step, the squared norm (lane 44)
+// Same operations in the same order on every sum.  LDS: the buffers live in what is dead during the refinement -- the
+// hypothesis matrices of the other rows / waves and the static filter's histogram.
+#define MW_SUB 16                        // points per step
+#define MW_NE 44                         // 36 J^T J + 8 J^T r entries
+#define MW_PROD (2 * MW_SUB * MW_NE)     // doubles per product buffer
+#define MW_MIN_ROWS 512                   // fewer inlier rows: wave 0 alone (measured break-even ~300 rows)
+template <int NW, bool LANES>
+__device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int lane, const float* rows, int count,
+                                           unsigned long long* prof) {
+  static_assert(NW == 4 && !LANES, "helper waves: the four-wave row form only");
+  static_assert(sizeof(RowMat) * (NW * NG - 1) >= sizeof(double) * (MW_PROD + NL * TS), "buffer 0 + second tile");
+  static_assert(sizeof(B.u) >= sizeof(double) * MW_PROD, "buffer 1");
+  SolveLds& S = B.s;
+  // (selects, not arrays of pointers: an indexed pointer array loses the LDS address space and turns every access into
+  // a FLAT instruction -- measured 3x slower)
+  double* const prod0 = reinterpret_cast<double*>(&B.m[0][1]);
+  double* const prod1 = reinterpret_cast<double*>(&B.u);
+  double* const Tb0 = S.T;
+  double* const Tb1 = prod0 + MW_PROD;
+#define MW_PRODBUF(i) (((i) & 1) ? prod1 : prod0)
+#define MW_TERMBUF(i) (((i) & 1) ? Tb1 : Tb0)
+  const int nsub = (count + MW_SUB - 1) / MW_SUB;
+  double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
+  if (wave == 1) { h0 = S.x[0]; h1 = S.x[1]; h2 = S.x[2]; h3 = S.x[3]; h4 = S.x[4]; h5 = S.x[5]; h6 = S.x[6]; h7 = S.x[7]; }
+  // producers: the two term indices of this lane's entry (wave 2: x-row, wave 3: y-row of J; J^T r: the residual)
+  int ia = 3, ib = 3;
+  if (wave >= 2 && lane < MW_NE) {
+    const bool yrow = wave == 3;
+    if (lane < 36) {
+      int ei, ej;
+      tri8(lane, ei, ej);
+      ia = yrow ? (ei < 3 ? 3 : ei < 6 ? ei - 3 : ei) : (ei < 3 ? ei : ei < 6 ? 3 : ei - 2);
+      ib = yrow ? (ej < 3 ? 3 : ej < 6 ? ej - 3 : ej) : (ej < 3 ? ej : ej < 6 ? 3 : ej - 2);
+    } else {
+      const int vi = lane - 36;
+      ia = yrow ? (vi < 3 ? 3 : vi < 6 ? vi - 3 : vi) : (vi < 3 ? vi : vi < 6 ? 3 : vi - 2);
+      ib = yrow ? 9 : 8;
+    }
+  }
+  double s = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, nrm = 0, rmax = 0;
+  float4 rnext = make_float4(0, 0, 0, 0);
+  for (int k = -2; k < nsub; k++) {
+    const unsigned long long pm0 = pf_now();
+    if (wave == 1) {
+      // rows of the tile whose terms are due at the next step (or now, for the first tile)
+      if (k == -2 || ((k + 3) & 3) == 0) {
+        const int i = ((k + 3) >> 2) * NL + lane;
+        if (i < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * i);
+      }
+      if (((k + 2) & 3) == 0 && ((k + 2) >> 2) * NL < count) {
+        const unsigned long long pm2 = pf_now();
+        const int n = (k + 2) >> 2, c0 = n * NL, i = c0 + lane;
+        double q0 = 0, q1 = 0;
+        if (i < count) {
+          const float4 r = rnext;
+          const double Mx = r.x, My = r.y;
+          double ww = h6 * Mx + h7 * My + 1.;
+          ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+          const double xi = (h0 * Mx + h1 * My + h2) * ww;
+          const double yi = (h3 * Mx + h4 * My + h5) * ww;
+          const double rx = xi - r.z, ry = yi - r.w;
+          double* t = MW_TERMBUF(n) + lane * TS;
+          t[8] = rx; t[9] = ry;
+          t[0] = Mx * ww; t[1] = My * ww; t[2] = ww; t[3] = 0.0;
+          t[4] = -Mx * ww * xi; t[5] = -My * ww * xi; t[6] = -Mx * ww * yi; t[7] = -My * ww * yi;
+          rmax = fmax(rmax, fabs(rx));
+          rmax = fmax(rmax, fabs(ry));
+          q0 = rx * rx; q1 = ry * ry;
+        }
+        const int cnt = min(NL, count - c0);
+        const double n0 = __shfl_down(q0, 1), n1 = __shfl_down(q1, 1);
+        if (!(lane & 1)) {
+          if (lane + 1 < cnt) S.P2[lane >> 1] = ((q0 + q1) + n0) + n1;
+          else if (lane < cnt) { S.P2[NL / 2] = q0; S.P2[NL / 2 + 1] = q1; }
+        }
+        pf_add_wave(prof, PF_MW_W1T, pf_now() - pm2);
+      }
+    } else if (wave == 0) {
+      if (k >= 0 && lane < MW_NE) {
+        // lanes 0..35: one J^T J entry each (one running sum); lanes 36..43: one J^T r entry each (four partial sums)
+        const double* r = MW_PRODBUF(k) + lane;
+        const int cnt = min(MW_SUB, count - k * MW_SUB);
+        if (cnt == MW_SUB) {
+          // all 32 words requested before the first addition (left alone the compiler waits for every pair of words in
+          // turn: sixteen LDS round trips per step)
+          double v[2 * MW_SUB];
+#pragma unroll
+          for (int q = 0; q < 2 * MW_SUB; q++) v[q] = r[q * MW_NE];
+          __builtin_amdgcn_sched_barrier(0);
+          if (lane < 36) {
+#pragma unroll
+            for (int q = 0; q < 2 * MW_SUB; q++) s += v[q];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 2 * MW_SUB; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+          }
+        } else {
+          int j = 0;
+          for (; j + 1 < cnt; j += 2) {
+            const double a = r[(2 * j) * MW_NE], b = r[(2 * j + 1) * MW_NE], c = r[(2 * j + 2) * MW_NE], d = r[(2 * j + 3) * MW_NE];
+            if (lane < 36) { s += a; s += b; s += c; s += d; }
+            else { s0 += a; s1 += b; s2 += c; s3 += d; }
+          }
+          if (j < cnt) {
+            const double a = r[(2 * j) * MW_NE], b = r[(2 * j + 1) * MW_NE];
+            if (lane < 36) { s += a; s += b; }
+            else { s0 += a; s0 += b; }
+          }
+        }
+      }
+      // the squared norm of tile n (pair sums left by wave 1 one step ago), in order, by a lane with nothing else to do
+      if (((k + 1) & 3) == 0 && ((k + 1) >> 2) * NL < count && lane == 44) {
+        const int cnt = min(NL, count - ((k + 1) >> 2) * NL), np = cnt >> 1;
+#pragma unroll 8
+        for (int g = 0; g < np; g++) nrm += S.P2[g];
+        if (cnt & 1) { nrm += S.P2[NL / 2]; nrm += S.P2[NL / 2 + 1]; }
+      }
+      pf_add(prof, PF_MW_W0, pf_now() - pm0); pf_add(prof, PF_MW_STEPS, 1);
+    } else {
+      const int sub = k + 1;
+      if (sub >= 0 && sub < nsub && lane < MW_NE) {
+        const double* t = MW_TERMBUF(sub >> 2) + (sub & 3) * MW_SUB * TS;
+        double* out = MW_PRODBUF(sub) + (wave - 2) * MW_NE + lane;
+        const int cnt = min(MW_SUB, count - sub * MW_SUB);
+        if (cnt == MW_SUB) {
+          double va[MW_SUB], vb[MW_SUB];
+#pragma unroll
+          for (int q = 0; q < MW_SUB; q++) { va[q] = t[q * TS + ia]; vb[q] = t[q * TS + ib]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < MW_SUB; q++) out[2 * q * MW_NE] = va[q] * vb[q];
+        } else {
+          for (int q = 0; q < cnt; q++) out[2 * q * MW_NE] = t[q * TS + ia] * t[q * TS + ib];
+        }
+      }
+      if (wave == 2) pf_add_wave(prof, PF_MW_PROD, pf_now() - pm0);
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && lane < 36) {
+    int ei, ej;
+    tri8(lane, ei, ej);
+    S.A8[ei * 8 + ej] = s; S.A8[ej * 8 + ei] = s;
+  }
+  if (wave == 0 && lane >= 36 && lane < MW_NE) S.v[lane - 36] = (s0 + s1 + s2 + s3) * 1.0;
+  if (wave == 0 && lane == 44) S.sc[0] = nrm;
+  if (wave == 1) {
+    for (int sft = 32; sft > 0; sft >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, sft));
+    if (lane == 44) S.sc[1] = rmax;
+  }
+  __syncthreads();
+#undef MW_PRODBUF
+#undef MW_TERMBUF
+}
+
+// The helper waves (1..NW-1) of a workgroup while wave 0 refines: they sleep at the workgroup barrier until wave 0 posts a
+// command in S.ib[4] (1: one lm_eval_mw pass over S.ib[5] rows of `crow`; 0: done).
+template <int NW, bool LANES>
+__device__ __forceinline__ void lm_helper_loop(BlockLds<NW, LANES>& B, int wave, int lane, const float* crow, unsigned long long* prof) {
+  if constexpr (NW == 4 && !LANES) {
+    for (;;) {
+      __syncthreads();
+      if (B.s.ib[4] == 0) break;
+      lm_eval_mw<NW, LANES>(B, wave, lane, crow, B.s.ib[5], prof);
+    }
+  }
+}
 
 // Hypotheses of one RANSAC call that were evaluated ahead of it by other workgroups (k_scan_hyp: the fixed-iteration
 // stream scan spreads the 2000 samples of a pair over ~140 workgroups; only the replay below is serial).
@@ -1318,10 +1501,30 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
       dlt_rows(S, B.m[0][0], lane, crow, ni, S.H, prof);  // keeps the RANSAC model when the refit is degenerate
       const unsigned long long pf3 = pf_now();
       pf_add(prof, PF_REFIT, pf3 - pf2);
-      const int it = lm_refine(S, B.m[0][0], lane, crow, ni, prof);
+      int it;
+      if constexpr (NW == 4 && !LANES) {
+        // the passes with the Jacobian run on all four waves: post the command, meet the helpers at the barrier
+        // (from MW_MIN_ROWS rows on: below that the extra barriers cost what the helpers save)
+        it = lm_refine(S, B.m[0][0], lane, crow, ni, prof, [&]() {
+          if (ni < MW_MIN_ROWS) { lm_eval(S, lane, crow, ni, S.x, true, 0, 1); return; }
+          if (lane == 0) { S.ib[4] = 1; S.ib[5] = ni; }
+          __threadfence_block();
+          __syncthreads();
+          lm_eval_mw<NW, LANES>(B, 0, lane, crow, ni, prof);
+        });
+      } else {
+        it = lm_refine(S, B.m[0][0], lane, crow, ni, prof, [&]() { lm_eval(S, lane, crow, ni, S.x, true, 0, 1); });
+      }
       pf_add(prof, PF_LM, pf_now() - pf3); pf_add(prof, PF_LM_ITERS, it);
       if (info && lane == 0) info[2] = it;
     }
+    if constexpr (NW == 4 && !LANES) {
+      if (lane == 0) S.ib[4] = 0;                          // release the helpers
+      __threadfence_block();
+      __syncthreads();
+    }
+  } else {
+    lm_helper_loop<NW, LANES>(B, wave, lane, crow, prof);
   }
   __threadfence_block();
   __syncthreads();
@@ -1831,10 +2034,12 @@ int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A_, int npairs, int
     const double n = h[PF_CALLS] ? (double)h[PF_CALLS] : 1.0;
     fprintf(stderr, "[evh ransac_final prof] calls %llu | per call (cycles): total %.0f hyp %.0f (chunks %.2f, dlt4+jacobi %.0f) "
             "compact %.0f refit %.0f lm %.0f (iters %.2f, solve8 %.0f, eval %.0f) | rotations: 9x9 %.1f 8x8 %.1f | chunk loop: rng %.0f "
-            "count %.0f barrier %.0f replay %.0f\n",
+            "count %.0f barrier %.0f replay %.0f | 4-wave eval: steps %.1f, per step wave0 %.0f producers %.0f, wave1 terms per call %.0f\n",
             h[PF_CALLS], h[PF_TOTAL] / n, h[PF_HYP] / n, h[PF_CHUNKS] / n, h[PF_SETUP] / n, h[PF_COMPACT] / n,
             h[PF_REFIT] / n, h[PF_LM] / n, h[PF_LM_ITERS] / n, h[PF_SOLVE8] / n, h[PF_EVAL] / n, h[PF_ROT9] / n,
-            h[PF_ROT8] / n, h[PF_RNG] / n, h[PF_COUNT] / n, h[PF_BARRIER] / n, h[PF_REPLAY] / n);
+            h[PF_ROT8] / n, h[PF_RNG] / n, h[PF_COUNT] / n, h[PF_BARRIER] / n, h[PF_REPLAY] / n, h[PF_MW_STEPS] / n,
+            h[PF_MW_W0] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1), h[PF_MW_PROD] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1),
+            h[PF_MW_W1T] / n);
   }
   return EVH_SUCCESS;
 }

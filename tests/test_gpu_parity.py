@@ -303,6 +303,35 @@ def test_find_homography_ransac(ctx):
             assert np.allclose(Hg, Ho, rtol=1e-9, atol=1e-12)
 
 
+def test_find_homography_many_inliers():
+    """From 512 inlier rows on, the refinement's passes with the Jacobian run on all four waves of the workgroup
+    (lm_eval_mw: products formed ahead by helper waves, additions in the operator's order).  Row counts on both sides of
+    that switch and with every kind of remainder (mod 2, 16, 64) against the oracle, bit for bit (utils.py:351-359)."""
+    from evenvizion_amd._lib import Context
+    rng = np.random.default_rng(77)
+    c = Context(device=0, max_w=1280, max_h=720, max_features=4000, max_frames=2)
+    try:
+        seen_mw = 0
+        for n in (520, 545, 560, 577, 600, 641, 705, 777, 1030, 1541, 2049, 3000, 3999):
+            Ht = S.random_h(rng, 1280)
+            a = rng.uniform(0, 1280, (n, 2))
+            p = (Ht @ np.c_[a, np.ones(n)].T).T
+            b = p[:, :2] / p[:, 2:] + rng.normal(0, 0.5, (n, 2))
+            nout = int(n * rng.uniform(0.0, 0.12))
+            if nout:
+                b[rng.choice(n, nout, replace=False)] = rng.uniform(0, 1280, (nout, 2))
+            pts = np.c_[a, b].astype(np.float32)
+            Hg, mg, ig = c.find_homography(dev(pts))
+            Ho, mo, io = O.find_homography(pts[:, :2], pts[:, 2:])
+            assert Ho is not None and Hg is not None
+            assert np.array_equal(mg, mo) and np.array_equal(ig, io), (n, ig, io)
+            assert np.array_equal(Hg, Ho), (n, np.abs(Hg - Ho).max())
+            seen_mw += int(mo.sum() >= 512)
+        assert seen_mw >= 8
+    finally:
+        c.close()
+
+
 def test_find_homography_fixed_iterations(ctx):
     """force_max_iters (BASELINE configs[2] "RANSAC 2000 iters"): every accepted sample up to max_iters is evaluated;
     the oracle's forced mode is the same loop without RANSACUpdateNumIters.  Also a short bound (37) that ends inside
