@@ -796,8 +796,16 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
     WSYNC();
     const int cnt = min(NL, count - c0);
     if (lane < 4) {
-#pragma unroll 8
-      for (int j = 0; j < cnt; j++) acc += T[j * TS + lane];
+      int j = 0;
+      for (; j + 8 <= cnt; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = T[(j + u) * TS + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+      }
+      for (; j < cnt; j++) acc += T[j * TS + lane];
     }
     WSYNC();
   }
@@ -814,8 +822,16 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
     WSYNC();
     const int cnt = min(NL, count - c0);
     if (lane < 4) {
-#pragma unroll 8
-      for (int j = 0; j < cnt; j++) dev += fabs(T[j * TS + lane] - mycen);
+      int j = 0;
+      for (; j + 8 <= cnt; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = T[(j + u) * TS + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) dev += fabs(v[u] - mycen);
+      }
+      for (; j < cnt; j++) dev += fabs(T[j * TS + lane] - mycen);
     }
     WSYNC();
   }
@@ -843,8 +859,19 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
     WSYNC();
     const int cnt = min(NL, count - c0);
     if (lane < 45) {
-#pragma unroll 4
-      for (int j = 0; j < cnt; j++) {
+      // four points' operands requested before the first product: the compiler otherwise waits for the LDS after every
+      // point (measured on lm_eval_mw's loops: one round trip per read group, 3x the time)
+      int j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        const double* t = T + j * TS;
+        double a[4], b[4], c[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = t[u * TS + lxj]; b[u] = t[u * TS + lxk]; c[u] = t[u * TS + lyj]; d[u] = t[u * TS + lyk]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) s += a[u] * b[u] + c[u] * d[u];
+      }
+      for (; j < cnt; j++) {
         const double* t = T + j * TS;
         s += t[lxj] * t[lxk] + t[lyj] * t[lyk];
       }
@@ -976,6 +1003,19 @@ __device__ __forceinline__ void lm_eval(SolveLds& S, int lane, const float* rows
     // and only the additions differ: one running sum in point order / four interleaved partial sums.
     if (role == 1 || role == 2) {
       int j = 0;
+      for (; j + 3 < cnt; j += 4) {               // two pairs of points per trip, their sixteen operands requested together
+        const double* t = T + j * TS;
+        double a[4], b[4], c[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = t[u * TS + pa]; b[u] = t[u * TS + pb]; c[u] = t[u * TS + pc]; d[u] = t[u * TS + pd]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+          const double P0 = a[u] * b[u], P1 = c[u] * d[u], P2 = a[u + 1] * b[u + 1], P3 = c[u + 1] * d[u + 1];
+          if (role == 1) { s += P0; s += P1; s += P2; s += P3; }
+          else { s0 += P0; s1 += P1; s2 += P2; s3 += P3; }
+        }
+      }
       for (; j + 1 < cnt; j += 2) {
         const double* t = T + j * TS;
         const double P0 = t[pa] * t[pb], P1 = t[pc] * t[pd], P2 = t[TS + pa] * t[TS + pb], P3 = t[TS + pc] * t[TS + pd];
