@@ -19,4 +19,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --kernel-trace --stats -d $O/stats3 -o stats3 --output-format csv -- python3 $R/bench.py --config 3 --steps 4 --warmup 1 --cpu-pairs 0 > $O/stats3.log 2>&1
 cd $R && python bench.py > $O/bench.json 2> $O/bench.err
 for c in 2 3 4 5; do python bench.py --config $c > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err || true; done
+python bench.py --config 3 --force-max-iters > $O/bench_cfg3_forced.json 2> $O/bench_cfg3_forced.err || true
+# probes: stream cases (adaptive / forced), several streams per call, host frames in / dict out, the three detector types
+python tools/stream_probe.py > $O/stream_probe.json 2> $O/stream_probe.err || true
+python tools/stream_probe.py 3840x2160:4000:0 3840x2160:4000:1 > $O/stream_probe_4k.json 2>> $O/stream_probe.err || true
+python tools/multi_stream_probe.py > $O/multi_stream_probe.json 2> $O/multi_stream_probe.err || true
+python tools/e2e_probe.py > $O/e2e_probe.json 2> $O/e2e_probe.err || true
+python tools/types_probe.py 400x224 > $O/types_probe.json 2> $O/types_probe.err || true
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/types_stats -o types --output-format csv -- python3 $R/tools/types_probe.py 400x224 > $O/types_stats.log 2>&1 || true)
 tail -1 $O/bench.json

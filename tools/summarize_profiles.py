@@ -160,4 +160,22 @@ if os.path.exists(b):
     except Exception:
         pass
     open(os.path.join(out, tag + "_bench_n1.json"), "w").write(json.dumps(d) + "\n")
+# 5. the other configs and the probes of the same collection run
+import shutil
+for name, dst in [("bench.json", "_bench_cfg1.json"), ("bench_cfg2.json", "_bench_cfg2.json"), ("bench_cfg3.json", "_bench_cfg3.json"),
+                  ("bench_cfg4.json", "_bench_cfg4.json"), ("bench_cfg5.json", "_bench_cfg5.json"),
+                  ("bench_cfg3_forced.json", "_bench_cfg3_forced.json"), ("stream_probe.json", "_stream_probe.json"),
+                  ("stream_probe_4k.json", "_stream_probe_4k.json"), ("multi_stream_probe.json", "_multi_stream_probe.json"),
+                  ("e2e_probe.json", "_e2e_probe.json"), ("types_probe.json", "_types_probe.json")]:
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 2:
+        txt = open(f).read().strip()
+        if name.startswith("bench"):
+            txt = txt.splitlines()[-1]          # the JSON line (bench.py prints nothing else on stdout)
+        open(os.path.join(out, tag + dst), "w").write(txt + "\n")
+f = find("types_stats", "*kernel_stats.csv")
+if f:
+    with open(f) as fi, open(os.path.join(out, tag + "_types_kernel_stats.csv"), "w") as fo:
+        fo.write("# rocprofv3 --kernel-trace --stats -- python3 tools/types_probe.py 400x224 (one 33-frame stream through ORB, SIFT, SURF and SURF+SIFT+ORB, 4 calls each)\n")
+        fo.write(fi.read())
 print("profiles/ updated with tag", tag)

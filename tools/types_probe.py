@@ -27,5 +27,7 @@ for wh in (sys.argv[1:] or ["400x224"]):
         dt = (time.perf_counter() - t) / 3
         res['%dx%d_%s' % (w, h, "+".join(feats))] = dict(pairs=nfr - 1, seconds=round(dt, 4), pairs_per_s=round((nfr - 1) / dt, 1),
                                                          ok=int((st == 0).sum()))
+    # key points per frame of each type (frame 1 of the last call): the sizes behind the matcher / scan times
+    res['%dx%d_keypoints_frame1' % (w, h)] = dict(SIFT=int(ctx.lib.evh_sift_count(ctx.h, 1)), SURF=int(ctx.lib.evh_surf_count(ctx.h, 1)))
     ctx.close()
 print(json.dumps(res, indent=1))
