@@ -45,6 +45,7 @@ void evo_orb_layout(int w, int h, int nfeatures, int* lw, int* lh, float* lscale
 int64_t evo_orb_pyramid(const uint8_t* gray, int w, int h, uint8_t* out);
 /* FAST-9/16 + 3x3 NMS on one image; row-major emission; returns count (may exceed cap; only cap written) */
 int evo_fast_nms(const uint8_t* img, int w, int h, int threshold, int* xs, int* ys, int* scores, int cap);
+void evo_fast_score_map(const uint8_t* img, int w, int h, int threshold, uint8_t* out);
 /* candidates after border filter + retainBest(2*quota) for one level, row-major; returns count */
 int evo_orb_level_candidates(const uint8_t* img, int w, int h, int quota, int* xs, int* ys, int* scores, int cap);
 /* 7x7/sigma=2 8-bit Gaussian blur with reflect-101 borders (K6 first half) */

@@ -453,6 +453,18 @@ extern "C" int evo_fast_nms(const uint8_t* img, int w, int h, int thr, int* xs, 
   return (int)c.size();
 }
 
+/* the map behind fast_nms: FAST-9/16 corner score at `thr` (0 where the pixel is not a corner); for the independent check of
+ * the corner predicate against skimage.feature.corner_fast (tests/golden/skimage_fast9.npz) */
+extern "C" void evo_fast_score_map(const uint8_t* img, int w, int h, int thr, uint8_t* out) {
+  memset(out, 0, (size_t)w * h);
+  if (w < 7 || h < 7) return;
+  for (int y = 3; y < h - 3; y++)
+    for (int x = 3; x < w - 3; x++) {
+      const uint8_t* p = img + (size_t)y * w + x;
+      if (fast_is_corner(p, w, thr)) out[(size_t)y * w + x] = (uint8_t)fast_score(p, w, thr);
+    }
+}
+
 extern "C" int evo_orb_level_candidates(const uint8_t* img, int w, int h, int quota, int* xs, int* ys, int* scores,
                                         int cap) {
   std::vector<Corner> c;

@@ -111,6 +111,15 @@ def fast_nms(img, threshold=20):
     return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
 
 
+def fast_score_map(img, threshold=20):
+    """FAST-9/16 corner score of every pixel at `threshold` (0 = not a corner), before the 3x3 non-maximum suppression."""
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().evo_fast_score_map(_p(img), w, h, int(threshold), _p(out))
+    return out
+
+
 def orb_level_candidates(img, quota):
     img = _u8(img)
     h, w = img.shape

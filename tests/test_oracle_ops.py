@@ -222,3 +222,53 @@ def test_sift_and_surf_restatements_are_geometrically_sound():
         assert abs(lib.evo_sift_exp32f(x) - np.exp(np.float32(x))) <= 4e-7 * np.exp(x)       # hal::exp32f: ~1e-7 relative
     for x in (0.0, 1 / 3, 0.5, 1.1666, -0.4):
         assert lib.evo_sift_exp2(x) == np.float32(2.0 ** np.float64(np.float32(x)))          # 2^x rounded to float
+
+
+def test_fast_corner_predicate_equals_skimage():
+    """Independent pin of the FAST-9/16 corner test (frame_processing.py:59-61 -> ORB -> FAST): the oracle's corner mask
+    equals, pixel for pixel, the mask of skimage.feature.corner_fast(n=9) -- scikit-image 0.18.3's own Cython
+    implementation, captured in the build container by tools/make_skimage_fixture.py into tests/golden/skimage_fast9.npz
+    (images included; blocks with plateaus and ties, smooth texture with isolated points and lines, noise at three
+    contrasts so that differences exactly at the threshold are frequent)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_fast9.npz"))
+    total = 0
+    for i in range(3):
+        img = d["img%d" % i]
+        h, w = img.shape
+        want = np.unpackbits(d["mask%d" % i])[:h * w].reshape(h, w).astype(bool)
+        score = O.fast_score_map(img, 20)
+        assert np.array_equal(score > 0, want), "image %d" % i
+        # the score is the largest threshold at which the pixel is still a corner (cornerScore: best arc's min |diff| - 1)
+        ys, xs = np.nonzero(score)
+        for y, x in list(zip(ys, xs))[::97]:
+            s = int(score[y, x])
+            assert s >= 20 and O.fast_score_map(img, s)[y, x] == s and O.fast_score_map(img, s + 1)[y, x] == 0
+        total += int(want.sum())
+    assert total > 10000
+
+
+def test_sift_scale_space_against_scipy():
+    """Independent sanity of the SIFT scale space (sigma schedule, octave chain; parity with OpenCV stays unpinned): layer i
+    of octave o equals a direct Gaussian of the documented absolute blur sigma_i = 1.6 * 2^(i/3) * 2^o (in pixels of the
+    doubled image, which itself carries blur 1.0), computed by scipy.ndimage in float64 from the doubled image.  The two
+    differ only by kernel truncation and float32 rounding: a few hundredths of a gray level."""
+    from scipy import ndimage
+    from evenvizion_amd import synthetic as S
+    _, cur, _ = S.make_pair(5, 160, 120)
+    pyr = O.sift_gauss_pyramid(cur)
+    assert pyr[0].shape == (6, 240, 320)
+    # the doubled image: recover it by undoing nothing -- blur it ourselves from the 2x bilinear upsample of the frame
+    up = ndimage.zoom(cur.astype(np.float64), 2, order=1, mode="nearest", grid_mode=True)
+    assert up.shape == (240, 320)
+    for i in range(6):
+        sig_abs = 1.6 * 2.0 ** (i / 3.0)
+        want = ndimage.gaussian_filter(up, np.sqrt(sig_abs ** 2 - 1.0), mode="mirror", truncate=5.0)
+        got = pyr[0][i].astype(np.float64)
+        inner = (slice(16, -16), slice(16, -16))                     # away from the border conventions of the upsample
+        assert np.abs(got[inner] - want[inner]).max() < 0.75, (i, np.abs(got[inner] - want[inner]).max())
+        assert np.abs(got[inner] - want[inner]).mean() < 0.05, (i, np.abs(got[inner] - want[inner]).mean())
+    # next octave = every second pixel of layer 3 (blur 2 * 1.6), then the same schedule
+    for o in range(1, len(pyr)):
+        hh, ww = pyr[o][0].shape                                     # (odd sizes round down)
+        assert np.array_equal(pyr[o][0], pyr[o - 1][3][::2, ::2][:hh, :ww])
