@@ -272,3 +272,49 @@ def test_sift_scale_space_against_scipy():
     for o in range(1, len(pyr)):
         hh, ww = pyr[o][0].shape                                     # (odd sizes round down)
         assert np.array_equal(pyr[o][0], pyr[o - 1][3][::2, ::2][:hh, :ww])
+
+
+def test_orb_orientation_and_brief_equal_skimage():
+    """Independent pin of ORB's orientation and descriptor stages (K5, K6; frame_processing.py:59-61): on the oracle's own
+    key points of a stored frame, scikit-image's corner_orientations gives the same intensity-centroid angle (within
+    fastAtan2's approximation error) and its Cython _orb_loop -- steered by the same angles, reading the oracle's blurred
+    level image -- gives the same 256 bits for every key point; the 1024 numbers of the sampling pattern (restated here
+    from the published table) equal scikit-image's copy.  Fixture: tests/golden/skimage_orb.npz, made by
+    tools/make_skimage_fixture.py in the build container."""
+    import os, re
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_orb.npz"))
+    kp = O.orb_detect(d["gray"], 500)
+    # the oracle's key points, regrouped by level like the fixture (stable within a level)
+    order = np.concatenate([np.nonzero(kp["octave"] == l)[0] for l in range(8)])
+    assert np.array_equal(kp["octave"][order], d["octave"]) and np.array_equal(kp["lx"][order], d["lx"]) \
+        and np.array_equal(kp["ly"][order], d["ly"]), "fixture is stale: regenerate it"
+    ang = np.deg2rad(kp["angle"][order].astype(np.float64))
+    diff = np.abs((ang - d["skimage_angle_rad"] + np.pi) % (2 * np.pi) - np.pi)
+    assert np.rad2deg(diff.max()) < 0.02                      # fastAtan2: <= 0.3 degrees by its contract, 0.01 in practice
+    assert np.array_equal(kp["desc"][order], d["skimage_desc"])
+    assert len(order) > 400 and len(np.unique(kp["octave"])) == 8
+    # the pattern table itself, both copies in the repo
+    root = os.path.join(os.path.dirname(__file__), "..")
+    txt = [l for l in open(os.path.join(root, "oracle", "orb_pattern.inc")) if not l.strip().startswith("//")]
+    mine = np.array([int(x) for x in re.findall(r"-?\d+", "".join(txt))][:1024]).reshape(256, 4)
+    assert np.array_equal(mine, d["skimage_pattern"].astype(int))
+    data = np.loadtxt(os.path.join(root, "evenvizion_amd", "data", "orb_pattern_31.txt"), dtype=int)
+    assert np.array_equal(data, d["skimage_pattern"].astype(int))
+
+
+def test_pyramid_resize_against_scipy():
+    """Independent sanity of the pyramid's `resize` (INTER_LINEAR_EXACT: pixel centres aligned, 8.8 fixed-point weights;
+    conventions, not bits) against scipy.ndimage.zoom(order=1, grid_mode=True) in float64: within one gray level
+    everywhere and unbiased.  (The descriptor stage's 8-bit Gaussian is NOT checked this way: its kernel, rounded tap by tap
+    as the operator's fixed-point path does, sums to 257/256 per pass -- a +0.8 % gain a float blur does not have.)"""
+    from scipy import ndimage
+    from evenvizion_amd import synthetic as S
+    _, cur, _ = S.make_pair(9, 400, 224)
+    pyr = O.orb_pyramid(cur)
+    for l in range(1, 4):
+        lh, lw = pyr[l].shape
+        ph, pw = pyr[l - 1].shape
+        want = ndimage.zoom(pyr[l - 1].astype(np.float64), (lh / ph, lw / pw), order=1, mode="nearest", grid_mode=True)
+        assert want.shape == (lh, lw)
+        diff = pyr[l].astype(np.float64) - want
+        assert np.abs(diff).max() <= 1.0 and abs(diff.mean()) < 0.05, (l, np.abs(diff).max(), diff.mean())
