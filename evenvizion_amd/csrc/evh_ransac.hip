@@ -762,7 +762,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // optional in-kernel cycle accounting (EVH_RANSAC_PROF=1): slots of A.prof, accumulated by thread 0
 enum { PF_CALLS = 0, PF_HYP, PF_CHUNKS, PF_COMPACT, PF_REFIT, PF_LM, PF_LM_ITERS, PF_SOLVE8, PF_EVAL, PF_TOTAL, PF_ROT9,
-       PF_ROT8, PF_SETUP, PF_RNG, PF_COUNT, PF_BARRIER, PF_REPLAY, PF_MW_W0, PF_MW_W1T, PF_MW_PROD, PF_MW_STEPS, PF_NSLOTS };
+       PF_ROT8, PF_SETUP, PF_RNG, PF_COUNT, PF_BARRIER, PF_REPLAY, PF_MW_W0, PF_MW_W1, PF_MW_W2, PF_MW_W3, PF_MW_WAIT, PF_MW_STEPS, PF_NSLOTS };
 __device__ __forceinline__ unsigned long long pf_now() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ void pf_add(unsigned long long* prof, int slot, unsigned long long v) {
   if (prof && threadIdx.x == 0) atomicAdd(prof + slot, v);
@@ -787,10 +787,13 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
   double* T = S.T;
   // centroids: lanes 0..3 own cm.x, cm.y, cM.x, cM.y  (m = b columns, M = a columns)
   double acc = 0;
+  const float4 first_rows = lane < count ? *reinterpret_cast<const float4*>(rows + 4 * lane) : make_float4(0, 0, 0, 0);
+  float4 rnext = first_rows;
   for (int c0 = 0; c0 < count; c0 += NL) {
     const int i = c0 + lane;
+    const float4 r = rnext;                       // requested one tile ahead
+    if (i + NL < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * (i + NL));
     if (i < count) {
-      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
       T[lane * TS + 0] = r.z; T[lane * TS + 1] = r.w; T[lane * TS + 2] = r.x; T[lane * TS + 3] = r.y;
     }
     WSYNC();
@@ -813,10 +816,12 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
   const double cmx = __shfl(acc, 0), cmy = __shfl(acc, 1), cMx = __shfl(acc, 2), cMy = __shfl(acc, 3);
   double dev = 0;
   const double mycen = lane == 0 ? cmx : lane == 1 ? cmy : lane == 2 ? cMx : cMy;
+  rnext = first_rows;
   for (int c0 = 0; c0 < count; c0 += NL) {
     const int i = c0 + lane;
+    const float4 r = rnext;                       // requested one tile ahead
+    if (i + NL < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * (i + NL));
     if (i < count) {
-      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
       T[lane * TS + 0] = r.z; T[lane * TS + 1] = r.w; T[lane * TS + 2] = r.x; T[lane * TS + 3] = r.y;
     }
     WSYNC();
@@ -846,10 +851,12 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
   const int lxj = ej < 3 ? ej : ej < 6 ? 3 : ej - 2, lxk = ek < 3 ? ek : ek < 6 ? 3 : ek - 2;
   const int lyj = ej < 3 ? 3 : ej < 6 ? ej - 3 : ej + 1, lyk = ek < 3 ? 3 : ek < 6 ? ek - 3 : ek + 1;
   double s = 0;
+  rnext = first_rows;
   for (int c0 = 0; c0 < count; c0 += NL) {
     const int i = c0 + lane;
+    const float4 r = rnext;
+    if (i + NL < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * (i + NL));
     if (i < count) {
-      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
       const double x = (r.z - cmx) * smx, y = (r.w - cmy) * smy;
       const double X = (r.x - cMx) * sMx, Y = (r.y - cMy) * sMy;
       double* t = T + lane * TS;
@@ -944,6 +951,22 @@ __device__ __forceinline__ void eig_solve8_wave(RowMat& M, int lane, const doubl
   pf_add(prof, PF_SOLVE8, pf_now() - pt0);
 }
 
+// acc + v[0] + v[1] + ... + v[n-1] in that order, the words requested sixteen at a time (the compiler alone waits for the
+// LDS after every single read of such a chain)
+__device__ __forceinline__ double add_in_order(double acc, const double* v, int n) {
+  int g = 0;
+  for (; g + 16 <= n; g += 16) {
+    double w[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) w[u] = v[g + u];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc += w[u];
+  }
+  for (; g < n; g++) acc += v[g];
+  return acc;
+}
+
 // One pass of the refinement callback over the rows at parameters h[0..7] (LDS): S.sc[slotS] = sum of squared
 // residuals (groups of four, as cv::norm), S.sc[slotR] = max |residual|; with J also S.A8 = J^T J (mirrored) and
 // S.v = J^T r (four interleaved partial sums).  Wave 0, all 64 lanes.  A point's terms in the tile:
@@ -964,11 +987,14 @@ __device__ __forceinline__ void lm_eval(SolveLds& S, int lane, const float* rows
   const int role = withJ && lane < 36 ? 1 : withJ && lane < 44 ? 2 : lane == 44 ? 3 : 0;
   const int pa = role == 1 ? jxi : role == 2 ? vx : 8, pb = role == 1 ? jxj : 8;
   const int pc = role == 1 ? jyi : role == 2 ? vy : 9, pd = role == 1 ? jyj : 9;
+  // the rows of the NEXT tile are requested before this tile is worked on (a tile used to start with a full memory round trip)
+  float4 rnext = lane < count ? *reinterpret_cast<const float4*>(rows + 4 * lane) : make_float4(0, 0, 0, 0);
   for (int c0 = 0; c0 < count; c0 += NL) {
     const int i = c0 + lane;
     double q0 = 0, q1 = 0;
+    const float4 r = rnext;
+    if (i + NL < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * (i + NL));
     if (i < count) {
-      const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
       const double Mx = r.x, My = r.y;
       double ww = h6 * Mx + h7 * My + 1.;
       ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
@@ -1029,9 +1055,7 @@ __device__ __forceinline__ void lm_eval(SolveLds& S, int lane, const float* rows
         else { s0 += P0; s0 += P1; }
       }
     } else if (role == 3) {
-      const int np = cnt >> 1;
-#pragma unroll 8
-      for (int g = 0; g < np; g++) nrm += S.P2[g];
+      nrm = add_in_order(nrm, S.P2, cnt >> 1);
       if (cnt & 1) { nrm += S.P2[NL / 2]; nrm += S.P2[NL / 2 + 1]; }
     }
     WSYNC();
@@ -1163,25 +1187,55 @@ struct BlockLds {
 
 // ---- lm_eval with the Jacobian, all four waves of the workgroup (round 3).  The sums of J^T J and J^T r are strictly
 // sequential over the points (the operator's order), but only their ADDITIONS are: the products are formed ahead by
-// other waves.  Steps of 16 points, one workgroup barrier per step, everything double-buffered:
-//   wave 1     terms of the next 64-point tile (every fourth step; its rows are requested one step ahead), max |r| and
-//              the pair sums of the squared residuals of that tile
-//   wave 2 / 3 the x- / y-row products of the 44 entries (lane = entry) for the 16 points of the NEXT step: all lanes
-//              read the same point's terms (10 words: no bank conflict) and write the product buffer of that step as [point][x|y][entry]
-//   wave 0     the additions of THIS step (lane = entry: 36 J^T J entries, one running sum in point order; 8 J^T r
-//              entries, four interleaved partial sums) and, every fourth step, the squared norm (lane 44)
+// another wave.  And most of the products are structural zeros: the x-row of J is (t0 t1 t2 0 0 0 t4 t5), the y-row
+// (0 0 0 t0 t1 t2 t6 t7), so of the 36 entries (i <= j) of J^T J  9 have no nonzero product at all, 24 have ONE per
+// point (x or y) and only (6,6), (6,7), (7,7) have both.  Adding +-0.0 to a running sum that started at +0.0 never
+// changes a bit of it (x + +-0 = x for x != 0, and +0 + -0 = +0), so the zero products are neither formed nor added:
+// 46 products per point instead of 88, 16 dependent additions per step instead of 32 for the 24 single entries.
+// (Finite terms assumed: 0 * inf would be NaN.  The terms are products of the rows, 1/w and the current parameters;
+// parameters that large have already failed the residual tests.)
+// Steps of 16 points, one workgroup barrier per step, everything double-buffered:
+//   wave 1  terms of the next 64-point tile (every fourth step; its rows are requested one step ahead), max |r| and the
+//           pair sums of the squared residuals of that tile
+//   wave 2  the 46 products (lane = product) for the 16 points of the NEXT step: all lanes read the same point's terms
+//           (10 words: no bank conflict) and write prod[point][46]: 24 singles, then (x, y) of 11 pair entries
+//   wave 0  this step's additions of the 24 single entries (lane = entry, one running sum in point order) and, every
+//           fourth step, the squared norm (lane 44)
+//   wave 3  this step's additions of the pair entries: (6,6), (6,7), (7,7) of J^T J (s += x; s += y) and the 8 entries of
+//           J^T r (four interleaved partial sums; their structural zeros are formed and added like any other value)
 // Same operations in the same order on every sum.  LDS: the buffers live in what is dead during the refinement -- the
 // hypothesis matrices of the other rows / waves and the static filter's histogram.
 #define MW_SUB 16                        // points per step
-#define MW_NE 44                         // 36 J^T J + 8 J^T r entries
-#define MW_PROD (2 * MW_SUB * MW_NE)     // doubles per product buffer
+#define MW_NS 24                         // single entries of J^T J
+#define MW_NP 11                         // pair entries: 3 of J^T J + 8 of J^T r
+#define MW_NPR (MW_NS + 2 * MW_NP)       // products per point
+#define MW_PROD (MW_SUB * MW_NPR)        // doubles per product buffer
 #define MW_MIN_ROWS 512                   // fewer inlier rows: wave 0 alone (measured break-even ~300 rows)
+__device__ __forceinline__ int mw_jx(int k) { return k < 3 ? k : k < 6 ? 3 : k - 2; }   // term index of J's x-row, column k
+__device__ __forceinline__ int mw_jy(int k) { return k < 3 ? 3 : k < 6 ? k - 3 : k; }   // ... y-row
+// the `which`-th entry (i <= j, tri8 order) of the given kind: 1 = x only, 2 = y only (both kinds enumerated together as
+// "single"), 0 = none; returns false when there is no such entry
+__device__ __forceinline__ bool mw_entry(int which, bool single, int& ei, int& ej, bool& yrow) {
+  int cnt = 0;
+  bool found = false;
+  for (int e = 0; e < 36; e++) {
+    int i, j;
+    tri8(e, i, j);
+    const bool cx = !(i >= 3 && i < 6) && !(j >= 3 && j < 6), cy = i >= 3 && j >= 3;
+    const bool is_single = cx != cy, is_none = !cx && !cy;
+    if (single ? is_single : is_none) {
+      if (cnt == which) { ei = i; ej = j; yrow = cy; found = true; }
+      cnt++;
+    }
+  }
+  return found;
+}
 template <int NW, bool LANES>
 __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int lane, const float* rows, int count,
                                            unsigned long long* prof) {
   static_assert(NW == 4 && !LANES, "helper waves: the four-wave row form only");
-  static_assert(sizeof(RowMat) * (NW * NG - 1) >= sizeof(double) * (MW_PROD + NL * TS), "buffer 0 + second tile");
-  static_assert(sizeof(B.u) >= sizeof(double) * MW_PROD, "buffer 1");
+  static_assert(sizeof(RowMat) * (NW * NG - 1) >= sizeof(double) * (MW_PROD + NL * TS) + 16, "buffer 0 + second tile");
+  static_assert(sizeof(B.u) >= sizeof(double) * MW_PROD + 16, "buffer 1");
   SolveLds& S = B.s;
   // (selects, not arrays of pointers: an indexed pointer array loses the LDS address space and turns every access into
   // a FLAT instruction -- measured 3x slower)
@@ -1194,23 +1248,34 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
   const int nsub = (count + MW_SUB - 1) / MW_SUB;
   double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
   if (wave == 1) { h0 = S.x[0]; h1 = S.x[1]; h2 = S.x[2]; h3 = S.x[3]; h4 = S.x[4]; h5 = S.x[5]; h6 = S.x[6]; h7 = S.x[7]; }
-  // producers: the two term indices of this lane's entry (wave 2: x-row, wave 3: y-row of J; J^T r: the residual)
-  int ia = 3, ib = 3;
-  if (wave >= 2 && lane < MW_NE) {
-    const bool yrow = wave == 3;
-    if (lane < 36) {
-      int ei, ej;
-      tri8(lane, ei, ej);
-      ia = yrow ? (ei < 3 ? 3 : ei < 6 ? ei - 3 : ei) : (ei < 3 ? ei : ei < 6 ? 3 : ei - 2);
-      ib = yrow ? (ej < 3 ? 3 : ej < 6 ? ej - 3 : ej) : (ej < 3 ? ej : ej < 6 ? 3 : ej - 2);
-    } else {
-      const int vi = lane - 36;
-      ia = yrow ? (vi < 3 ? 3 : vi < 6 ? vi - 3 : vi) : (vi < 3 ? vi : vi < 6 ? 3 : vi - 2);
-      ib = yrow ? 9 : 8;
+  // wave 2: the two term indices of this lane's product.  wave 0: where this lane's sum goes in A8 (lanes 24..32: the
+  // entries that are zero by structure).  wave 3: lanes 0..2 = (6,6), (6,7), (7,7); lanes 3..10 = J^T r entry lane - 3.
+  int ia = 3, ib = 3, a8i = -1, a8j = -1;
+  if (wave == 2) {
+    if (lane < MW_NS) {
+      int ei = 0, ej = 0; bool yrow = false;
+      mw_entry(lane, true, ei, ej, yrow);
+      ia = yrow ? mw_jy(ei) : mw_jx(ei); ib = yrow ? mw_jy(ej) : mw_jx(ej);
+    } else if (lane < MW_NPR) {
+      const int u = (lane - MW_NS) >> 1;
+      const bool yrow = (lane - MW_NS) & 1;
+      if (u < 3) {
+        const int ei = u == 2 ? 7 : 6, ej = u == 0 ? 6 : 7;
+        ia = yrow ? mw_jy(ei) : mw_jx(ei); ib = yrow ? mw_jy(ej) : mw_jx(ej);
+      } else {
+        ia = yrow ? mw_jy(u - 3) : mw_jx(u - 3); ib = yrow ? 9 : 8;
+      }
     }
+  } else if (wave == 0) {
+    bool yrow = false;
+    if (lane < MW_NS) mw_entry(lane, true, a8i, a8j, yrow);
+    else if (lane < MW_NS + 9) mw_entry(lane - MW_NS, false, a8i, a8j, yrow);
+  } else if (wave == 3 && lane < 3) {
+    a8i = lane == 2 ? 7 : 6; a8j = lane == 0 ? 6 : 7;
   }
   double s = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, nrm = 0, rmax = 0;
   float4 rnext = make_float4(0, 0, 0, 0);
+  unsigned long long pf_busy = 0, pf_wait = 0;       // cycle accounting: summed in registers, one atomic per pass
   for (int k = -2; k < nsub; k++) {
     const unsigned long long pm0 = pf_now();
     if (wave == 1) {
@@ -1220,7 +1285,6 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
         if (i < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * i);
       }
       if (((k + 2) & 3) == 0 && ((k + 2) >> 2) * NL < count) {
-        const unsigned long long pm2 = pf_now();
         const int n = (k + 2) >> 2, c0 = n * NL, i = c0 + lane;
         double q0 = 0, q1 = 0;
         if (i < count) {
@@ -1245,54 +1309,64 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
           if (lane + 1 < cnt) S.P2[lane >> 1] = ((q0 + q1) + n0) + n1;
           else if (lane < cnt) { S.P2[NL / 2] = q0; S.P2[NL / 2 + 1] = q1; }
         }
-        pf_add_wave(prof, PF_MW_W1T, pf_now() - pm2);
       }
     } else if (wave == 0) {
-      if (k >= 0 && lane < MW_NE) {
-        // lanes 0..35: one J^T J entry each (one running sum); lanes 36..43: one J^T r entry each (four partial sums)
+      if (k >= 0 && lane < MW_NS) {
         const double* r = MW_PRODBUF(k) + lane;
         const int cnt = min(MW_SUB, count - k * MW_SUB);
         if (cnt == MW_SUB) {
-          // all 32 words requested before the first addition (left alone the compiler waits for every pair of words in
-          // turn: sixteen LDS round trips per step)
-          double v[2 * MW_SUB];
+          // all words requested before the first addition (left alone the compiler waits for every read in turn)
+          double v[MW_SUB];
 #pragma unroll
-          for (int q = 0; q < 2 * MW_SUB; q++) v[q] = r[q * MW_NE];
+          for (int q = 0; q < MW_SUB; q++) v[q] = r[q * MW_NPR];
           __builtin_amdgcn_sched_barrier(0);
-          if (lane < 36) {
 #pragma unroll
-            for (int q = 0; q < 2 * MW_SUB; q++) s += v[q];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 2 * MW_SUB; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
-          }
+          for (int q = 0; q < MW_SUB; q++) s += v[q];
         } else {
-          int j = 0;
-          for (; j + 1 < cnt; j += 2) {
-            const double a = r[(2 * j) * MW_NE], b = r[(2 * j + 1) * MW_NE], c = r[(2 * j + 2) * MW_NE], d = r[(2 * j + 3) * MW_NE];
-            if (lane < 36) { s += a; s += b; s += c; s += d; }
-            else { s0 += a; s1 += b; s2 += c; s3 += d; }
-          }
-          if (j < cnt) {
-            const double a = r[(2 * j) * MW_NE], b = r[(2 * j + 1) * MW_NE];
-            if (lane < 36) { s += a; s += b; }
-            else { s0 += a; s0 += b; }
-          }
+          for (int q = 0; q < cnt; q++) s += r[q * MW_NPR];
         }
       }
       // the squared norm of tile n (pair sums left by wave 1 one step ago), in order, by a lane with nothing else to do
       if (((k + 1) & 3) == 0 && ((k + 1) >> 2) * NL < count && lane == 44) {
-        const int cnt = min(NL, count - ((k + 1) >> 2) * NL), np = cnt >> 1;
-#pragma unroll 8
-        for (int g = 0; g < np; g++) nrm += S.P2[g];
+        const int cnt = min(NL, count - ((k + 1) >> 2) * NL);
+        nrm = add_in_order(nrm, S.P2, cnt >> 1);
         if (cnt & 1) { nrm += S.P2[NL / 2]; nrm += S.P2[NL / 2 + 1]; }
       }
-      pf_add(prof, PF_MW_W0, pf_now() - pm0); pf_add(prof, PF_MW_STEPS, 1);
+    } else if (wave == 3) {
+      if (k >= 0 && lane < MW_NP) {
+        const double* r = MW_PRODBUF(k) + MW_NS + 2 * lane;              // (x, y) of point q at r[q * MW_NPR], +1
+        const int cnt = min(MW_SUB, count - k * MW_SUB);
+        if (cnt == MW_SUB) {
+          double vx[MW_SUB], vy[MW_SUB];
+#pragma unroll
+          for (int q = 0; q < MW_SUB; q++) { vx[q] = r[q * MW_NPR]; vy[q] = r[q * MW_NPR + 1]; }
+          __builtin_amdgcn_sched_barrier(0);
+          if (lane < 3) {
+#pragma unroll
+            for (int q = 0; q < MW_SUB; q++) { s += vx[q]; s += vy[q]; }
+          } else {
+#pragma unroll
+            for (int q = 0; q < MW_SUB; q += 2) { s0 += vx[q]; s1 += vy[q]; s2 += vx[q + 1]; s3 += vy[q + 1]; }
+          }
+        } else {
+          int q = 0;
+          for (; q + 1 < cnt; q += 2) {
+            const double a = r[q * MW_NPR], b = r[q * MW_NPR + 1], c = r[(q + 1) * MW_NPR], d = r[(q + 1) * MW_NPR + 1];
+            if (lane < 3) { s += a; s += b; s += c; s += d; }
+            else { s0 += a; s1 += b; s2 += c; s3 += d; }
+          }
+          if (q < cnt) {
+            const double a = r[q * MW_NPR], b = r[q * MW_NPR + 1];
+            if (lane < 3) { s += a; s += b; }
+            else { s0 += a; s0 += b; }
+          }
+        }
+      }
     } else {
       const int sub = k + 1;
-      if (sub >= 0 && sub < nsub && lane < MW_NE) {
+      if (sub >= 0 && sub < nsub && lane < MW_NPR) {
         const double* t = MW_TERMBUF(sub >> 2) + (sub & 3) * MW_SUB * TS;
-        double* out = MW_PRODBUF(sub) + (wave - 2) * MW_NE + lane;
+        double* out = MW_PRODBUF(sub) + lane;
         const int cnt = min(MW_SUB, count - sub * MW_SUB);
         if (cnt == MW_SUB) {
           double va[MW_SUB], vb[MW_SUB];
@@ -1300,22 +1374,22 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
           for (int q = 0; q < MW_SUB; q++) { va[q] = t[q * TS + ia]; vb[q] = t[q * TS + ib]; }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < MW_SUB; q++) out[2 * q * MW_NE] = va[q] * vb[q];
+          for (int q = 0; q < MW_SUB; q++) out[q * MW_NPR] = va[q] * vb[q];
         } else {
-          for (int q = 0; q < cnt; q++) out[2 * q * MW_NE] = t[q * TS + ia] * t[q * TS + ib];
+          for (int q = 0; q < cnt; q++) out[q * MW_NPR] = t[q * TS + ia] * t[q * TS + ib];
         }
       }
-      if (wave == 2) pf_add_wave(prof, PF_MW_PROD, pf_now() - pm0);
     }
+    const unsigned long long pm1 = pf_now();
     __syncthreads();
+    pf_busy += pm1 - pm0; pf_wait += pf_now() - pm1;
   }
-  if (wave == 0 && lane < 36) {
-    int ei, ej;
-    tri8(lane, ei, ej);
-    S.A8[ei * 8 + ej] = s; S.A8[ej * 8 + ei] = s;
-  }
-  if (wave == 0 && lane >= 36 && lane < MW_NE) S.v[lane - 36] = (s0 + s1 + s2 + s3) * 1.0;
+  pf_add_wave(prof, PF_MW_W0 + wave, pf_busy);
+  if (wave == 0) { pf_add(prof, PF_MW_WAIT, pf_wait); pf_add(prof, PF_MW_STEPS, nsub + 2); }
+  if (wave == 0 && a8i >= 0) { S.A8[a8i * 8 + a8j] = s; S.A8[a8j * 8 + a8i] = s; }      // (s = 0 for the structural zeros)
   if (wave == 0 && lane == 44) S.sc[0] = nrm;
+  if (wave == 3 && lane < 3) { S.A8[a8i * 8 + a8j] = s; S.A8[a8j * 8 + a8i] = s; }
+  if (wave == 3 && lane >= 3 && lane < MW_NP) S.v[lane - 3] = (s0 + s1 + s2 + s3) * 1.0;
   if (wave == 1) {
     for (int sft = 32; sft > 0; sft >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, sft));
     if (lane == 44) S.sc[1] = rmax;
@@ -2074,12 +2148,13 @@ int evh_launch_ransac_final(evh_ctx* c, const EvhRansacArgs& A_, int npairs, int
     const double n = h[PF_CALLS] ? (double)h[PF_CALLS] : 1.0;
     fprintf(stderr, "[evh ransac_final prof] calls %llu | per call (cycles): total %.0f hyp %.0f (chunks %.2f, dlt4+jacobi %.0f) "
             "compact %.0f refit %.0f lm %.0f (iters %.2f, solve8 %.0f, eval %.0f) | rotations: 9x9 %.1f 8x8 %.1f | chunk loop: rng %.0f "
-            "count %.0f barrier %.0f replay %.0f | 4-wave eval: steps %.1f, per step wave0 %.0f producers %.0f, wave1 terms per call %.0f\n",
+            "count %.0f barrier %.0f replay %.0f | 4-wave eval: steps %.1f, busy per step wave0 (singles) %.0f wave1 (terms) %.0f wave2 (products) %.0f wave3 (pairs) %.0f, wave0 at the barrier %.0f\n",
             h[PF_CALLS], h[PF_TOTAL] / n, h[PF_HYP] / n, h[PF_CHUNKS] / n, h[PF_SETUP] / n, h[PF_COMPACT] / n,
             h[PF_REFIT] / n, h[PF_LM] / n, h[PF_LM_ITERS] / n, h[PF_SOLVE8] / n, h[PF_EVAL] / n, h[PF_ROT9] / n,
             h[PF_ROT8] / n, h[PF_RNG] / n, h[PF_COUNT] / n, h[PF_BARRIER] / n, h[PF_REPLAY] / n, h[PF_MW_STEPS] / n,
-            h[PF_MW_W0] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1), h[PF_MW_PROD] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1),
-            h[PF_MW_W1T] / n);
+            h[PF_MW_W0] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1), h[PF_MW_W1] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1),
+            h[PF_MW_W2] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1), h[PF_MW_W3] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1),
+            h[PF_MW_WAIT] / (double)(h[PF_MW_STEPS] ? h[PF_MW_STEPS] : 1));
   }
   return EVH_SUCCESS;
 }
