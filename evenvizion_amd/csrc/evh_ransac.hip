@@ -1210,7 +1210,9 @@ struct BlockLds {
 #define MW_NP 11                         // pair entries: 3 of J^T J + 8 of J^T r
 #define MW_NPR (MW_NS + 2 * MW_NP)       // products per point
 #define MW_PROD (MW_SUB * MW_NPR)        // doubles per product buffer
+#ifndef MW_MIN_ROWS
 #define MW_MIN_ROWS 512                   // fewer inlier rows: wave 0 alone (measured break-even ~300 rows)
+#endif
 __device__ __forceinline__ int mw_jx(int k) { return k < 3 ? k : k < 6 ? 3 : k - 2; }   // term index of J's x-row, column k
 __device__ __forceinline__ int mw_jy(int k) { return k < 3 ? 3 : k < 6 ? k - 3 : k; }   // ... y-row
 // the `which`-th entry (i <= j, tri8 order) of the given kind: 1 = x only, 2 = y only (both kinds enumerated together as
