@@ -111,10 +111,20 @@ __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
 
 // BruteForce knnMatch(q, t, 2) on float32 descriptors (matching.py:102-108 with SIFT / SURF rows): hal::normL2Sqr_ --
 // two 4-lane partial sums over steps of 8 elements, (d0 + d1) then its four lanes added left to right -- dist = sqrt,
-// insertion on strictly smaller dist.  One thread per query (its row in registers); the train rows are wave-uniform
-// and come through scalar loads.
+// insertion on strictly smaller dist.  A workgroup owns 64 queries (thread = query, its row in registers); its four
+// waves split the train rows into four consecutive ranges, each wave streams its range through its own double-buffered
+// LDS tile (coalesced 16-byte loads one tile ahead, then every lane reads the same row: broadcast) and keeps the
+// best two of its range; the ranges are merged in index order with the same strict insertion, which is the serial
+// result (the best two under (distance, index)).  Round 3: the first form fed the train rows through scalar loads with
+// one wave per SIMD and waited 2.4 us per train row (1.78 ms per 32 pairs of 749 x 749 rows).
+#define KF_TILE 8                                    // train rows per staged tile
 template <int DIM>
-__global__ __launch_bounds__(64) void k_knn2_f32(EvhKnnF32Args A) {
+__global__ __launch_bounds__(256) void k_knn2_f32(EvhKnnF32Args A) {
+  constexpr int R4 = DIM / 4;                        // float4 per row
+  constexpr int PER_LANE = KF_TILE * R4 / 64;        // float4 a lane moves per tile
+  __shared__ float4 s_t[4][2][KF_TILE * R4];
+  __shared__ float s_b[3][2][64];
+  __shared__ int s_i[3][2][64];
   const int p = blockIdx.y;
   int nq = A.nq, nt = A.nt;
   const float* Qb = A.q; const float* Tb = A.t;
@@ -125,8 +135,9 @@ __global__ __launch_bounds__(64) void k_knn2_f32(EvhKnnF32Args A) {
     Qb += (int64_t)qs * A.slot_floats; Tb += (int64_t)ts * A.slot_floats;
     oidx += (int64_t)p * A.out_stride * 2; odist += (int64_t)p * A.out_stride * 2;
   }
-  if ((int)blockIdx.x * 64 >= nq) return;
-  const int qi = blockIdx.x * 64 + threadIdx.x;
+  if ((int)blockIdx.x * 64 >= nq) return;            // workgroup-uniform
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x * 64 + lane;
   const bool act = qi < nq;
   // two-element vectors: the compiler emits v_pk_add_f32 / v_pk_mul_f32 (two IEEE f32 operations per lane and issue slot,
   // no contraction); the pairs are neighbouring elements, so every one of the eight running sums still sees exactly
@@ -135,31 +146,84 @@ __global__ __launch_bounds__(64) void k_knn2_f32(EvhKnnF32Args A) {
   v2f q[DIM / 2];
   const float4* Q = reinterpret_cast<const float4*>(Qb + (int64_t)(act ? qi : 0) * DIM);
 #pragma unroll
-  for (int k = 0; k < DIM / 4; k++) { const float4 v = Q[k]; q[2 * k] = v2f{v.x, v.y}; q[2 * k + 1] = v2f{v.z, v.w}; }
+  for (int k = 0; k < R4; k++) { const float4 v = Q[k]; q[2 * k] = v2f{v.x, v.y}; q[2 * k + 1] = v2f{v.z, v.w}; }
   float b0 = FLT_MAX, b1 = FLT_MAX;
   int i0 = -1, i1 = -1;
-  for (int j = 0; j < nt; j++) {
-    const v2f* t = reinterpret_cast<const v2f*>(Tb + (int64_t)j * DIM);
-    v2f d0a = {0.f, 0.f}, d0b = {0.f, 0.f}, d1a = {0.f, 0.f}, d1b = {0.f, 0.f};   // d0[0..1], d0[2..3], d1[0..1], d1[2..3]
+  const int per = (nt + 3) >> 2, j0 = wave * per, j1 = min(nt, j0 + per);
+  const int ntile = j1 > j0 ? (j1 - j0 + KF_TILE - 1) / KF_TILE : 0;
+  const float4* T4 = reinterpret_cast<const float4*>(Tb);
+  // the tile in flight: named registers (as an array -- through a lambda or a macro alike -- the compiler kept it in scratch)
+  static_assert(PER_LANE == 2 || PER_LANE == 4, "64 or 128 floats per row");
+  float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
+#define KF_LD(tile_, u) T4[(int64_t)min(j0 + (tile_) * KF_TILE + ((u) * 64 + lane) / R4, j1 - 1) * R4 + (((u) * 64 + lane) % R4)]
+#define KF_LOAD_TILE(tile_)                                      /* rows past the range: its last row again (never used) */ \
+  {                                                                                                                        \
+    p0 = KF_LD(tile_, 0); p1 = KF_LD(tile_, 1);                                                                            \
+    if constexpr (PER_LANE == 4) { p2 = KF_LD(tile_, 2); p3 = KF_LD(tile_, 3); }                                           \
+  }
+  if (ntile > 0) KF_LOAD_TILE(0)
+  for (int tile = 0; tile < ntile; tile++) {
+    float4* buf = s_t[wave][tile & 1];
+    buf[lane] = p0; buf[64 + lane] = p1;
+    if constexpr (PER_LANE == 4) { buf[128 + lane] = p2; buf[192 + lane] = p3; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tile + 1 < ntile) KF_LOAD_TILE(tile + 1)
+    const int jb = j0 + tile * KF_TILE, cnt = min(KF_TILE, j1 - jb);
+    for (int r = 0; r < cnt; r++) {
+      const float4* row = buf + r * R4;
+      v2f d0a = {0.f, 0.f}, d0b = {0.f, 0.f}, d1a = {0.f, 0.f}, d1b = {0.f, 0.f};   // d0[0..1], d0[2..3], d1[0..1], d1[2..3]
+      // the row in batches of 16 words x 4: all reads of a batch requested before its arithmetic (the compiler alone waits
+      // after every LDS read), a whole row at once would not fit the registers next to the query
+      constexpr int HB = R4 < 16 ? R4 : 16;
 #pragma unroll
-    for (int k = 0; k < DIM / 2; k += 4) {
-      const v2f e0 = q[k] - t[k], e1 = q[k + 1] - t[k + 1], e2 = q[k + 2] - t[k + 2], e3 = q[k + 3] - t[k + 3];
-      d0a = d0a + e0 * e0;
-      d0b = d0b + e1 * e1;
-      d1a = d1a + e2 * e2;
-      d1b = d1b + e3 * e3;
-    }
-    const float d0[4] = {d0a.x, d0a.y, d0b.x, d0b.y}, d1[4] = {d1a.x, d1a.y, d1b.x, d1b.y};
-    const float u0 = d0[0] + d1[0], u1 = d0[1] + d1[1], u2 = d0[2] + d1[2], u3 = d0[3] + d1[3];
-    const float ds = sqrtf(u0 + u1 + u2 + u3);
-    if (ds < b1) {
-      if (b0 > ds) { b1 = b0; i1 = i0; b0 = ds; i0 = j; }
-      else { b1 = ds; i1 = j; }
+      for (int h = 0; h < R4; h += HB) {
+        float4 tv[HB];
+#pragma unroll
+        for (int k = 0; k < HB; k++) tv[k] = row[h + k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < HB; k += 2) {
+          const v2f e0 = q[2 * (h + k)] - v2f{tv[k].x, tv[k].y}, e1 = q[2 * (h + k) + 1] - v2f{tv[k].z, tv[k].w};
+          const v2f e2 = q[2 * (h + k) + 2] - v2f{tv[k + 1].x, tv[k + 1].y}, e3 = q[2 * (h + k) + 3] - v2f{tv[k + 1].z, tv[k + 1].w};
+          d0a = d0a + e0 * e0;
+          d0b = d0b + e1 * e1;
+          d1a = d1a + e2 * e2;
+          d1b = d1b + e3 * e3;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const float u0 = d0a.x + d1a.x, u1 = d0a.y + d1a.y, u2 = d0b.x + d1b.x, u3 = d0b.y + d1b.y;
+      const float ds = sqrtf(u0 + u1 + u2 + u3);
+      const int j = jb + r;
+      if (ds < b1) {
+        if (b0 > ds) { b1 = b0; i1 = i0; b0 = ds; i0 = j; }
+        else { b1 = ds; i1 = j; }
+      }
     }
   }
-  if (act) {
-    oidx[2 * qi] = i0; oidx[2 * qi + 1] = i1;
-    odist[2 * qi] = b0; odist[2 * qi + 1] = b1;
+#undef KF_LOAD_TILE
+#undef KF_LD
+  // ranges in index order: wave 0 inserts the best two of waves 1, 2, 3 with the same rule
+  if (wave > 0) { s_b[wave - 1][0][lane] = b0; s_i[wave - 1][0][lane] = i0; s_b[wave - 1][1][lane] = b1; s_i[wave - 1][1][lane] = i1; }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const float ds = s_b[w][e][lane];
+        const int j = s_i[w][e][lane];
+        if (j >= 0 && ds < b1) {
+          if (b0 > ds) { b1 = b0; i1 = i0; b0 = ds; i0 = j; }
+          else { b1 = ds; i1 = j; }
+        }
+      }
+    if (act) {
+      oidx[2 * qi] = i0; oidx[2 * qi + 1] = i1;
+      odist[2 * qi] = b0; odist[2 * qi + 1] = b1;
+    }
   }
 }
 
@@ -333,8 +397,8 @@ int evh_launch_knn2_f32(evh_ctx* c, const EvhKnnF32Args& A, int npairs) {
   const int nq_max = A.n_arr ? (int)A.out_stride : A.nq;
   if (nq_max <= 0 || npairs <= 0) return EVH_SUCCESS;
   const dim3 grid((nq_max + 63) / 64, npairs);
-  if (A.dim == 128) hipLaunchKernelGGL(k_knn2_f32<128>, grid, dim3(64), 0, c->stream, A);
-  else if (A.dim == 64) hipLaunchKernelGGL(k_knn2_f32<64>, grid, dim3(64), 0, c->stream, A);
+  if (A.dim == 128) hipLaunchKernelGGL(k_knn2_f32<128>, grid, dim3(256), 0, c->stream, A);
+  else if (A.dim == 64) hipLaunchKernelGGL(k_knn2_f32<64>, grid, dim3(256), 0, c->stream, A);
   else return evh_fail(c, EVH_ERR_UNSUPPORTED, "float descriptors: 64 or 128 elements per row (SURF / SIFT)");
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
