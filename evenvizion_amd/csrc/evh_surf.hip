@@ -309,7 +309,11 @@ struct DescLds {
   float dir, sin_dir, cos_dir, scale;
 };
 
-__global__ __launch_bounds__(256) void k_surf_describe(SurfArgs A, int f0) {
+// Two launches per group: key points whose window has at most SU_WINSMALL rows (nearly all of them: sizes up to ~45) with a
+// small dynamic LDS -- five workgroups per compute unit instead of one -- and the few larger ones with the full buffer; a
+// workgroup whose key point belongs to the other launch leaves at once.
+constexpr int SU_WINSMALL = 128;
+__global__ __launch_bounds__(256) void k_surf_describe(SurfArgs A, int f0, int win_lo, int win_hi) {
   extern __shared__ float s_rowbuf[];              // [win_size][21] horizontal INTER_AREA sums (float, or int bits on the integer path)
   __shared__ DescLds S;
   const int gf = blockIdx.y, f = f0 + gf, ki = blockIdx.x, tid = threadIdx.x;
@@ -318,6 +322,11 @@ __global__ __launch_bounds__(256) void k_surf_describe(SurfArgs A, int f0) {
   const float cx = rec[0], cy = rec[1], size = rec[2];
   const int srows = A.h + 1, scols = A.w + 1;
   const float s = size * 1.2f / 9.0f;
+  {
+    const int win_class = (int)((float)(SU_PATCH + 1) * s);       // = `win` below; out-of-range windows (never emitted) go with the large class
+    const bool small = win_class >= 1 && win_class <= SU_WINSMALL;
+    if (small ? win_lo != 0 : win_hi != SU_WINMAX) return;
+  }
   const int g = 2 * (int)rintf(2 * s);
   const int* sum = A.sum + (int64_t)gf * A.sum_frame_ints;
   // ---- orientation samples, kept in kk order
@@ -636,7 +645,7 @@ int evh_launch_surf(evh_ctx* c, int nframes, int w, int h, float hessian_thresho
   A.raw = c->d_surf_raw; A.nraw = c->d_surf_nraw; A.srt = c->d_surf_srt; A.kp = c->d_surf_kp; A.xy = c->d_surf_xy;
   A.desc = c->d_surf_desc; A.count = c->d_surf_count; A.flags = c->d_surf_flags; A.cap = c->surf_cap;
   EVH_HIP(c, hipMemsetAsync(c->d_surf_nraw, 0, sizeof(int) * (size_t)nframes, s));
-  const size_t lds = sizeof(float) * 21 * SU_WINMAX;
+  const size_t lds = sizeof(float) * 21 * SU_WINMAX, lds_small = sizeof(float) * 21 * SU_WINSMALL;
   EVH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_surf_describe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   for (int f0 = 0; f0 < nframes; f0 += c->surf_group) {
     const int ng = std::min(c->surf_group, nframes - f0);
@@ -647,7 +656,8 @@ int evh_launch_surf(evh_ctx* c, int nframes, int w, int h, float hessian_thresho
     hipLaunchKernelGGL(k_surf_maxima, dim3((w + 63) / 64, (h + 3) / 4, SU_OCT * SU_LAY * ng), dim3(256), 0, s, A, f0, hessian_threshold);
     hipLaunchKernelGGL(k_surf_rank, dim3((c->surf_cap + 255) / 256, ng), dim3(256), 0, s, A, f0);
     hipLaunchKernelGGL(k_surf_compact, dim3(ng), dim3(1024), 0, s, A, f0);
-    hipLaunchKernelGGL(k_surf_describe, dim3(c->surf_cap, ng), dim3(256), lds, s, A, f0);
+    hipLaunchKernelGGL(k_surf_describe, dim3(c->surf_cap, ng), dim3(256), lds_small, s, A, f0, 0, SU_WINSMALL);
+    hipLaunchKernelGGL(k_surf_describe, dim3(c->surf_cap, ng), dim3(256), lds, s, A, f0, SU_WINSMALL, SU_WINMAX);
     EVH_HIP(c, hipGetLastError());
   }
   c->surf_frames_resident = nframes;
