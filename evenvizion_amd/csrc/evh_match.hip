@@ -297,14 +297,28 @@ __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
     if (tid == 0) { A.npts[p] = 0; A.status[p] = EVH_PAIR_FEW_MATCHES; }
     return;
   }
-  // remove_double_matching: key = exact (ax, ay); first occurrence keeps its place, last occurrence gives b
+  // remove_double_matching: key = exact (ax, ay); first occurrence keeps its place, last occurrence gives b.  The x
+  // coordinates of the m survivors are staged in LDS (the claim counters are dead); a thread walks them eight at a time
+  // and looks at y -- a gather from global memory -- only where x matches.  (Both coordinates gathered from global memory
+  // in the inner loop cost 1.4 ms on 1 000 SIFT survivors.)
+  float* sx = reinterpret_cast<float*>(claims);
+  for (int i = tid; i < m; i += 256) sx[i] = xyq[2 * mq[i]];
+  __syncthreads();
   for (int i = tid; i < m; i += 256) {
-    float ax = xyq[2 * mq[i]], ay = xyq[2 * mq[i] + 1];
+    const float ax = sx[i], ay = xyq[2 * mq[i] + 1];
     int first = 1, last = i;
-    for (int j = 0; j < m; j++) {
-      float bx = xyq[2 * mq[j]], by = xyq[2 * mq[j] + 1];
-      if (bx == ax && by == ay) { if (j < i) first = 0; if (j > last) last = j; }
+    int j = 0;
+    for (; j + 8 <= m; j += 8) {
+      float bx[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) bx[u] = sx[j + u];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (bx[u] == ax && xyq[2 * mq[j + u] + 1] == ay) { if (j + u < i) first = 0; if (j + u > last) last = j + u; }
     }
+    for (; j < m; j++)
+      if (sx[j] == ax && xyq[2 * mq[j] + 1] == ay) { if (j < i) first = 0; if (j > last) last = j; }
     keep[i] = first; lastj[i] = last;
   }
   __syncthreads();
@@ -353,6 +367,7 @@ __global__ __launch_bounds__(256) void k_accumulate(EvhAccArgs A) {
 // key = exact (ax, ay), first occurrence keeps its place, the LAST occurrence gives b
 __global__ __launch_bounds__(256) void k_merge(EvhMergeArgs A) {
   __shared__ int wave_tot[4];
+  __shared__ float2 s_xy[1024];                  // a tile of the rows' (ax, ay): every thread compares its row against all of them
   const int p = blockIdx.x, tid = threadIdx.x;
   const int st = A.accstatus[p];
   if (st != 0) {
@@ -365,13 +380,29 @@ __global__ __launch_bounds__(256) void k_merge(EvhMergeArgs A) {
   int u = 0;
   for (int c0 = 0; c0 < m; c0 += 256) {          // workgroup-uniform
     const int i = c0 + tid;
-    bool first = false; int last = i;
-    if (i < m) {
-      const float ax = R[i].x, ay = R[i].y;
-      first = true;
-      for (int j = 0; j < m; j++) {
-        const float4 o = R[j];
-        if (o.x == ax && o.y == ay) { if (j < i) first = false; if (j > last) last = j; }
+    bool first = i < m; int last = i;
+    const float ax = i < m ? R[i].x : 0.f, ay = i < m ? R[i].y : 0.f;
+    // (the rows used to come one by one from global memory inside this loop: 1.25 ms on 1 900 rows)
+    for (int t0 = 0; t0 < m; t0 += 1024) {
+      const int tn = min(1024, m - t0);
+      __syncthreads();
+      for (int k = tid; k < tn; k += 256) { const float4 o = R[t0 + k]; s_xy[k] = make_float2(o.x, o.y); }
+      __syncthreads();
+      if (i < m) {
+        int j = 0;
+        for (; j + 8 <= tn; j += 8) {
+          float2 o[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) o[q] = s_xy[j + q];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (o[q].x == ax && o[q].y == ay) { if (t0 + j + q < i) first = false; if (t0 + j + q > last) last = t0 + j + q; }
+        }
+        for (; j < tn; j++) {
+          const float2 o = s_xy[j];
+          if (o.x == ax && o.y == ay) { if (t0 + j < i) first = false; if (t0 + j > last) last = t0 + j; }
+        }
       }
     }
     const int slot = block_ordered_slot(first, wave_tot, u);
