@@ -1920,11 +1920,12 @@ __global__ __launch_bounds__(NL) void k_scan_init(EvhRansacArgs A, ScanWs W) {
 
 // the sample quadruples of every pair of the batch, all pairs at once (getSubset: they depend on the row count only, so
 // they can be drawn before the scan reaches the pair)
-__global__ __launch_bounds__(NL) void k_scan_quads(EvhRansacArgs A, int npairs, int pitch, ScanWs W) {
+__global__ __launch_bounds__(NL) void k_scan_quads(EvhRansacArgs A, int npairs, int pitch, ScanWs W, int phase1) {
+  // phase1: the tables of RANSAC #1 of independent pairs (row counts in A.npts, one "stream" of one pair per block)
   const int b = blockIdx.x, s = b / npairs, p = b - s * npairs, lane = threadIdx.x;
   const int64_t slot = (int64_t)s * pitch + p;
   if (A.status[slot] != EVH_PAIR_OK) return;
-  const int n = A.npts2[slot];
+  const int n = phase1 ? A.npts[slot] : A.npts2[slot];
   if (n <= 4) return;
   Rng rng;
   const FastMod fm((unsigned)n);
@@ -2042,6 +2043,74 @@ __global__ __launch_bounds__(4 * NL) void k_scan_finish(EvhRansacArgs A, int p, 
   if (p == npairs - 1 && A.state_out && tid < 9) { A.state_out[18 * s + tid] = B.Hsup[tid]; A.state_out[18 * s + 9 + tid] = B.Hprev[tid]; }
 }
 
+// ---- fixed-iteration RANSAC #1 of a SMALL batch of pairs (a stream chunk): the same split -- k_static_hyp evaluates one
+// 16-hypothesis chunk per workgroup (grid: chunks x pairs), k_static_finish replays, refines and runs the static filter.
+// (One workgroup per pair with per-lane solvers is the throughput form for hundreds of pairs; alone it takes 4.8 ms.)
+__global__ __launch_bounds__(4 * NL) void k_static_hyp(EvhRansacArgs A, ScanWs W) {
+  BlockLds<4, false>& B = block_lds<4, false>();
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15, p = blockIdx.y;
+  if (A.status[p] != EVH_PAIR_OK) return;
+  const int n = A.npts[p];
+  if (n <= 4) return;
+  const float* use = A.pts + (int64_t)p * A.row_stride * 4;
+  double thr = A.thr;
+  if (thr <= 0) thr = 3;
+  const float t = (float)(thr * thr);
+  const int hg = blockIdx.x * (4 * NG) + wave * NG + row;
+  const ushort4 q = W.quads[(int64_t)p * W.hmax + hg];
+  const int my[4] = {q.x, q.y, q.z, q.w};
+  float Mx[4], My[4], mx[4], my_[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float4 r = *reinterpret_cast<const float4*>(use + 4 * my[i]);
+    Mx[i] = r.x; My[i] = r.y; mx[i] = r.z; my_[i] = r.w;
+  }
+  const bool valid = check_subset4(Mx, My, mx, my_);
+  double H[9];
+  const bool ok = dlt4_rows(B.m[wave][row], lane, valid, Mx, My, mx, my_, H);
+  int good = 0;
+  if (ok) {
+    float Hf[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+#pragma unroll 4
+    for (int i = gl; i < n; i += GL) {
+      const float4 r = *reinterpret_cast<const float4*>(use + 4 * i);
+      good += is_inlier(Hf, r.x, r.y, r.z, r.w, t) ? 1 : 0;
+    }
+  }
+  good = rsum16(good);
+  if (gl == 0) {
+    W.hyp[(int64_t)p * W.hmax + hg] = (int)((valid ? 0x80000000u : 0u) | (ok ? 0x40000000u : 0u) | (unsigned)good);
+    double* Ho = W.hypH + ((int64_t)p * W.hmax + hg) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; i++) Ho[i] = ok ? H[i] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(4 * NL) void k_static_finish(EvhRansacArgs A, ScanWs W) {
+  BlockLds<4, false>& B = block_lds<4, false>();
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (A.status[p] != EVH_PAIR_OK) { if (tid == 0) A.npts2[p] = 0; return; }
+  const int n = A.npts[p];
+  const float* rows = A.pts + (int64_t)p * A.row_stride * 4;
+  float* out = A.pts2 + (int64_t)p * A.row_stride * 4;
+  uint8_t* mask = A.mask + (int64_t)p * A.row_stride;
+  float* crow = A.crow + (int64_t)p * A.row_stride * 4;
+  int* rbin = reinterpret_cast<int*>(A.lm + (int64_t)p * A.row_stride * 4);
+  int* info = A.info ? A.info + 8 * p : nullptr;
+  const ScanPre pre{W.hyp + (int64_t)p * W.hmax, W.hypH + (int64_t)p * W.hmax * 9, W.hmax, n > 4 ? W.rng_after[p] : 0ull};
+  const bool found = find_homography_block<4, false>(B, rows, n, A.thr, A.max_iters, A.conf, A.force_max, mask, crow, info, A.prof,
+                                                     nullptr, n > 4 ? &pre : nullptr);
+  if (!found) {
+    if (tid == 0) { A.status[p] = EVH_PAIR_NO_PROVISIONAL_H; A.npts2[p] = 0; }
+    return;
+  }
+  if (A.H1 && tid < 9) A.H1[9 * p + tid] = B.s.H[tid];
+  const int m = static_filter_block<4, false>(B, B.s.H, rows, n, rbin, out);
+  if (tid == 0) A.npts2[p] = m;
+}
+
 // waves per workgroup: enough rows to cover the handful of hypotheses an adaptive RANSAC needs in one chunk when the
 // launch is small (latency), one wave per pair when the launch fills the chip anyway (throughput); with the iteration
 // count forced, four waves of lane-per-hypothesis solvers (256 hypotheses per chunk)
@@ -2069,19 +2138,35 @@ int scan_ws(evh_ctx* c, int nstreams, int npairs, int hmax, ScanWs* W) {
   return EVH_SUCCESS;
 }
 
-int launch_forced_scan(evh_ctx* c, const EvhRansacArgs& A, int npairs, int nstreams, int pitch) {
-  if (A.row_stride > 65536) return evh_fail(c, EVH_ERR_INVALID, "fixed-iteration scan: more than 65536 rows per pair");
-  // enough chunks for max_iters counted samples plus 1/8 of rejected ones; a pair that needs more continues inside
-  // k_scan_finish with the ordinary chunk loop
+// enough 16-hypothesis chunks for max_iters counted samples plus 1/8 of rejected ones; a pair that needs more continues
+// inside the finishing kernel with the ordinary chunk loop
+int forced_chunks(const EvhRansacArgs& A) {
   const int iters = A.max_iters > 0 ? A.max_iters : 1;
   int chunks = (iters + iters / 8 + 4 * NG - 1) / (4 * NG) + 1;
-  if (const char* e = getenv("EVH_SCAN_CHUNKS")) chunks = atoi(e) > 0 ? atoi(e) : chunks;   // tests: a short table, the rest in k_scan_finish
-  if (chunks > 608) chunks = 608;                                   // < 10000 samples (ScanPre)
+  if (const char* e = getenv("EVH_SCAN_CHUNKS")) chunks = atoi(e) > 0 ? atoi(e) : chunks;   // tests: a short table, the rest in the finishing kernel
+  return chunks > 608 ? 608 : chunks;                               // < 10000 samples (ScanPre)
+}
+
+int launch_forced_static(evh_ctx* c, const EvhRansacArgs& A, int npairs) {
+  if (A.row_stride > 65536) return evh_fail(c, EVH_ERR_INVALID, "fixed-iteration RANSAC: more than 65536 rows per pair");
+  const int chunks = forced_chunks(A);
+  ScanWs W;
+  int rc = scan_ws(c, npairs, 1, chunks * 4 * NG, &W);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scan_quads, dim3(npairs), dim3(NL), 0, c->stream, A, 1, 1, W, 1);
+  hipLaunchKernelGGL(k_static_hyp, dim3(chunks, npairs), dim3(4 * NL), 0, c->stream, A, W);
+  hipLaunchKernelGGL(k_static_finish, dim3(npairs), dim3(4 * NL), 0, c->stream, A, W);
+  return EVH_SUCCESS;
+}
+
+int launch_forced_scan(evh_ctx* c, const EvhRansacArgs& A, int npairs, int nstreams, int pitch) {
+  if (A.row_stride > 65536) return evh_fail(c, EVH_ERR_INVALID, "fixed-iteration scan: more than 65536 rows per pair");
+  const int chunks = forced_chunks(A);
   ScanWs W;
   int rc = scan_ws(c, nstreams, npairs, chunks * 4 * NG, &W);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scan_init, dim3(nstreams), dim3(NL), 0, c->stream, A, W);
-  hipLaunchKernelGGL(k_scan_quads, dim3(nstreams * npairs), dim3(NL), 0, c->stream, A, npairs, pitch, W);
+  hipLaunchKernelGGL(k_scan_quads, dim3(nstreams * npairs), dim3(NL), 0, c->stream, A, npairs, pitch, W, 0);
   for (int p = 0; p < npairs; p++) {
     hipLaunchKernelGGL(k_scan_hyp, dim3(chunks, nstreams), dim3(4 * NL), 0, c->stream, A, p, npairs, pitch, W);
     hipLaunchKernelGGL(k_scan_finish, dim3(nstreams), dim3(4 * NL), 0, c->stream, A, p, npairs, pitch, W);
@@ -2113,6 +2198,12 @@ int evh_launch_static_filter(evh_ctx* c, const double* d_H, const float* d_rows,
 int evh_launch_ransac_static(evh_ctx* c, const EvhRansacArgs& A, int npairs) {
   if (npairs <= 0) return EVH_SUCCESS;
   if (A.force_max && !A.lane_v) return evh_fail(c, EVH_ERR_HIP, "fixed-iteration RANSAC: the per-lane scratch could not be allocated");
+  if (A.force_max && npairs <= 256 && !getenv("EVH_SCAN_ONE_WG")) {        // a stream chunk: spread the samples of every pair
+    const int fr = launch_forced_static(c, A, npairs);
+    if (fr) return fr;
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
   EVH_LAUNCH_NW(waves_for(npairs, A.force_max), k_ransac_static, npairs, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
