@@ -170,6 +170,34 @@ def test_multi_type_stream_vs_oracle(features):
         c.close()
 
 
+def test_multi_type_fixed_iteration_forms_agree(monkeypatch):
+    """The fixed-iteration mode through the multi-type path: RANSAC #1 of every type and the scan spread their samples over
+    workgroups (k_static_hyp / k_scan_hyp + the finishing kernels, 1 000-2 000 rows per pair here, so the four-wave
+    refinement passes run too).  No oracle form of this combination exists; the spread form must equal the
+    single-workgroup kernels (EVH_SCAN_ONE_WG=1), which the ORB tests pin against the oracle, bit for bit -- also with a
+    short hypothesis table (EVH_SCAN_CHUNKS=5: the rest of the samples inside the finishing kernels)."""
+    w, h = 400, 224
+    frames, _ = S.make_stream(33, 4, w, h)
+    n = len(frames) - 1
+    c = make_ctx(w, h, frames=len(frames), sift=4096)
+    try:
+        outs = []
+        for env in ({"EVH_SCAN_ONE_WG": "1"}, {}, {"EVH_SCAN_CHUNKS": "5"}):
+            monkeypatch.delenv("EVH_SCAN_CHUNKS", raising=False); monkeypatch.delenv("EVH_SCAN_ONE_WG", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+            st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+            c.stream_homography_batch_types(dev(frames), H, st, ["SIFT", "ORB"], force_max_iters=True)
+            c.synchronize()
+            outs.append((H.cpu().numpy(), st.cpu().numpy()))
+        assert list(outs[0][1]) == [0] * n
+        for H, st in outs[1:]:
+            assert np.array_equal(st, outs[0][1]) and np.array_equal(H, outs[0][0])
+    finally:
+        c.close()
+
+
 def test_multi_type_independent_pairs_and_bgr():
     w, h = 400, 224
     fr, _ = S.make_pair_batch(7, 2, w, h)
