@@ -728,6 +728,29 @@ def test_fixed_iteration_scan_forms(monkeypatch):
         c.close()
 
 
+def test_fixed_iteration_stream_of_20_frames(monkeypatch):
+    """A longer fixed-iteration stream (19 pairs per call: RANSAC #1 of all of them spread over 141 x 19 workgroups, then
+    the scan pair by pair) against the oracle, and the single-workgroup kernels on the same frames."""
+    from evenvizion_amd._lib import Context
+    w, h = 400, 224
+    fr, _ = S.make_stream(41, 20, w, h)
+    n = len(fr) - 1
+    Ho, so, rc = O.stream_gray(fr, force_max_iters=True)
+    assert rc == -1 and n >= 16
+    c = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=len(fr))
+    try:
+        for env in ({}, {"EVH_SCAN_ONE_WG": "1"}):
+            monkeypatch.delenv("EVH_SCAN_ONE_WG", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            H = torch.zeros(n, 9, dtype=torch.float64, device="cuda"); st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+            c.stream_homography_batch(dev(fr), H, st, force_max_iters=True); c.synchronize()
+            assert np.array_equal(st.cpu().numpy(), so), env
+            assert np.allclose(H.cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12), env
+    finally:
+        c.close()
+
+
 def test_resize_area(ctx):
     rng = np.random.default_rng(4)
     for (sw, sh, width, cn) in [(1170, 658, 400, 3), (1280, 720, 320, 3), (800, 600, 400, 1), (900, 300, 300, 3),
