@@ -1947,9 +1947,13 @@ __global__ __launch_bounds__(NL) void k_scan_quads(EvhRansacArgs A, int npairs, 
   if (lane == 0) W.rng_after[b] = after;
 }
 
+// LDS of the hypothesis kernels: the 16 row matrices and nothing else (23 KB: seven workgroups per compute unit; the
+// full BlockLds of the finishing kernels would allow three)
+struct HypLds { RowMat m[4][NG]; double Hsup[9]; };
+
 // one chunk of 16 hypotheses (a 16-lane row each) of pair p per workgroup; grid (hmax / 16, nstreams)
 __global__ __launch_bounds__(4 * NL) void k_scan_hyp(EvhRansacArgs A, int p, int npairs, int pitch, ScanWs W) {
-  BlockLds<4, false>& B = block_lds<4, false>();
+  __shared__ HypLds B;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15, s = blockIdx.y;
   const ScanState& T = W.state[s];
   if (T.aborted) return;
@@ -2047,7 +2051,7 @@ __global__ __launch_bounds__(4 * NL) void k_scan_finish(EvhRansacArgs A, int p, 
 // 16-hypothesis chunk per workgroup (grid: chunks x pairs), k_static_finish replays, refines and runs the static filter.
 // (One workgroup per pair with per-lane solvers is the throughput form for hundreds of pairs; alone it takes 4.8 ms.)
 __global__ __launch_bounds__(4 * NL) void k_static_hyp(EvhRansacArgs A, ScanWs W) {
-  BlockLds<4, false>& B = block_lds<4, false>();
+  __shared__ HypLds B;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15, p = blockIdx.y;
   if (A.status[p] != EVH_PAIR_OK) return;
   const int n = A.npts[p];
