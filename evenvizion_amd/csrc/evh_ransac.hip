@@ -1179,7 +1179,7 @@ struct BlockLds {
   double Hsup[9], Hprev[9], Hcur[9];
   int have_prev, gate;
   union {
-    struct { unsigned hist[HB]; unsigned first[HB]; } h;   // static filter: population and first member of every bin
+    struct { unsigned hist[HB]; } h;                       // static filter: population of every displacement bin
     double lmat[LANES ? NW * LM_ELEMS * NL : 1];            // the per-lane matrices (dead when the static filter runs)
   } u;
   unsigned long long red[NW];
@@ -1661,7 +1661,7 @@ template <int NW, bool LANES>
 __device__ __forceinline__ int static_filter_block(BlockLds<NW, LANES>& B, const double* H /*LDS*/, const float* rows, int n, int* rbin,
                                    float* out) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NT = NW * NL;
-  for (int i = tid; i < HB; i += NT) { B.u.h.hist[i] = 0u; B.u.h.first[i] = 0xFFFFFFFFu; }
+  for (int i = tid; i < HB; i += NT) B.u.h.hist[i] = 0u;
   __syncthreads();
   int big = 0;
   for (int i = tid; i < n; i += NT) {
@@ -1671,21 +1671,20 @@ __device__ __forceinline__ int static_filter_block(BlockLds<NW, LANES>& B, const
     double dist = sqrt(dx * dx + dy * dy);
     const int r = (int)__builtin_rint(dist);  // Python round(): half to even
     rbin[i] = r;
-    if ((unsigned)r < (unsigned)HB) { atomicAdd(&B.u.h.hist[r], 1u); atomicMin(&B.u.h.first[r], (unsigned)i); }
+    if ((unsigned)r < (unsigned)HB) atomicAdd(&B.u.h.hist[r], 1u);
     else big = 1;
   }
   __threadfence_block();
   big = __syncthreads_or(big);
   if (n == 0) return 0;
-  // most populated bin; ties -> the bin whose first member comes first
+  // most populated bin; ties -> the bin whose first member comes first.  key = population << 32 | (0x7FFFFFFF - first
+  // member): the largest key over the POINTS (a point carries the population of its own bin) is the largest over the
+  // bins -- no per-bin "first member" table is needed (it cost 8 KB of LDS in every solver workgroup)
   unsigned long long bestkey = 0;
   if (!big) {
-    for (int b = tid; b < HB; b += NT) {
-      const unsigned cnt = B.u.h.hist[b];
-      if (cnt) {
-        const unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0x7FFFFFFF - (int)B.u.h.first[b]);
-        bestkey = key > bestkey ? key : bestkey;
-      }
+    for (int i = tid; i < n; i += NT) {
+      const unsigned long long key = ((unsigned long long)B.u.h.hist[rbin[i]] << 32) | (unsigned)(0x7FFFFFFF - i);
+      bestkey = key > bestkey ? key : bestkey;
     }
   } else {
     for (int i = tid; i < n; i += NT) {
