@@ -272,8 +272,8 @@ int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int s
 int ensure_multitype(evh_ctx* c) {
   if (c->mt.cap) return EVH_SUCCESS;
   const int each = std::max(c->kcap, std::max(c->sift_cap, c->surf_cap)), cap = c->kcap + c->sift_cap + c->surf_cap;
-  if ((size_t)each * 5 * sizeof(int) > 150 * 1024)
-    return evh_fail(c, EVH_ERR_CAPACITY, "multi-type pairs: at most 7680 key points per frame and type in the matching filter");
+  if (each > 65535)
+    return evh_fail(c, EVH_ERR_CAPACITY, "multi-type pairs: at most 65535 key points per frame and type");
   const size_t P = (size_t)c->max_frames, K = (size_t)cap;
   int rc;
 #define M_(call) if ((rc = (call)) != EVH_SUCCESS) return rc
@@ -486,7 +486,7 @@ void evh_destroy(evh_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
                   c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
-                  c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch, c->d_scan_ws};
+                  c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch, c->d_scan_ws, c->d_filter_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   evh_sift_free(c);
   evh_surf_free(c);
@@ -770,7 +770,7 @@ int evh_ratio_unique_filter(evh_ctx* c, const int32_t* d_idx, const uint32_t* d_
   if (!c || !d_idx || !d_d2 || !d_xy_q || !d_xy_t || !d_pts || !h_count || !h_status || nq < 0 || nt < 0)
     return evh_fail(c, EVH_ERR_INVALID, "evh_ratio_unique_filter: bad argument");
   const int kc = std::max(std::max(nq, nt), 1);
-  if ((size_t)kc * 5 * sizeof(int) > 150 * 1024) return evh_fail(c, EVH_ERR_CAPACITY, "evh_ratio_unique_filter: too many rows");
+  if (kc > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "evh_ratio_unique_filter: too many rows");
   if (((uintptr_t)d_pts) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_pts must be 16-byte aligned");
   int* d_cnt = reinterpret_cast<int*>(c->d_small);
   EvhFilterArgs F{};
@@ -1108,7 +1108,7 @@ int evh_ratio_unique_filter_f32(evh_ctx* c, const int32_t* d_idx, const float* d
   if (!c || !d_idx || !d_dist || !d_xy_q || !d_xy_t || !d_pts || !h_count || !h_status || nq < 0 || nt < 0)
     return evh_fail(c, EVH_ERR_INVALID, "evh_ratio_unique_filter_f32: bad argument");
   const int kc = std::max(std::max(nq, nt), 1);
-  if ((size_t)kc * 5 * sizeof(int) > 150 * 1024) return evh_fail(c, EVH_ERR_CAPACITY, "evh_ratio_unique_filter_f32: too many rows");
+  if (kc > 65535) return evh_fail(c, EVH_ERR_CAPACITY, "evh_ratio_unique_filter_f32: too many rows");
   if (((uintptr_t)d_pts) & 15) return evh_fail(c, EVH_ERR_INVALID, "d_pts must be 16-byte aligned");
   int* d_cnt = reinterpret_cast<int*>(c->d_small);
   EvhFilterArgs F{};

@@ -29,7 +29,9 @@ struct EvhFilterArgs {
   int* npts; int* status;
   int kcap;                       // LDS sizing: >= max(nq, nt)
   int d2_is_dist;                 // d2 holds the float32 bits of the (square-rooted) distance: float descriptors
+  int* work;                      // k_filter<true>: global work arrays, 5 * kcap ints per pair (set by evh_launch_filter)
 };
+#define EVH_FILTER_LDS_MAX (150 * 1024)   // 5 * kcap ints of LDS: up to 7 680 key points per frame; beyond that a global scratch
 
 // BruteForce 2-NN on float32 descriptors (SIFT / SURF rows of `dim` floats, dim = 64 or 128)
 struct EvhKnnF32Args {

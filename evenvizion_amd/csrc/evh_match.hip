@@ -244,10 +244,16 @@ __device__ __forceinline__ int block_ordered_slot(bool flag, int* wave_tot /*[4]
 }
 
 // ratio test + one-to-one filter + duplicate-coordinate filter; one workgroup per pair.
+// GLOBAL: the five work arrays in a global scratch (A.work, 5 * kcap ints per pair) instead of LDS -- for key-point budgets
+// above 7 680 per frame (SIFT on frames wider than ~500 px), where 5 * kcap ints no longer fit a compute unit's LDS.  A
+// template, not a runtime pointer choice: generic pointers would turn the LDS form's accesses into FLAT instructions.
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
   extern __shared__ uint32_t dyn[];
-  // dynamic LDS layout: claims[kcap] | mq[kcap] | mt[kcap] | keep[kcap] | lastj[kcap]
-  int* claims = reinterpret_cast<int*>(dyn);
+  // work arrays: claims[kcap] | mq[kcap] | mt[kcap] | keep[kcap] | lastj[kcap]
+  int* claims;
+  if constexpr (GLOBAL) claims = A.work + (int64_t)blockIdx.x * 5 * A.kcap;
+  else claims = reinterpret_cast<int*>(dyn);
   int* mq = claims + A.kcap;
   int* mt = mq + A.kcap;
   int* keep = mt + A.kcap;
@@ -449,13 +455,26 @@ int evh_launch_merge(evh_ctx* c, const EvhMergeArgs& A, int npairs) {
   return EVH_SUCCESS;
 }
 
-int evh_launch_filter(evh_ctx* c, const EvhFilterArgs& A, int npairs) {
+int evh_launch_filter(evh_ctx* c, const EvhFilterArgs& A_, int npairs) {
   if (npairs <= 0) return EVH_SUCCESS;
+  EvhFilterArgs A = A_;
   size_t lds = sizeof(int) * 5 * (size_t)A.kcap;
+  if (lds > EVH_FILTER_LDS_MAX) {          // beyond a compute unit's LDS: the work arrays in a global scratch, grown on demand
+    const size_t need = lds * (size_t)npairs;
+    if (c->filter_ws_bytes < need) {
+      if (c->d_filter_ws) { EVH_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_filter_ws); c->d_filter_ws = nullptr; c->filter_ws_bytes = 0; }
+      EVH_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_filter_ws), need));
+      c->filter_ws_bytes = need;
+    }
+    A.work = c->d_filter_ws;
+    hipLaunchKernelGGL(k_filter<true>, dim3(npairs), dim3(256), 0, c->stream, A);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
   if (lds > 48 * 1024)   // large key-point budgets (N = 4000 -> ~105 KB): opt in to more dynamic LDS than the default
-    EVH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter), hipFuncAttributeMaxDynamicSharedMemorySize,
+    EVH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-  hipLaunchKernelGGL(k_filter, dim3(npairs), dim3(256), lds, c->stream, A);
+  hipLaunchKernelGGL(k_filter<false>, dim3(npairs), dim3(256), lds, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
 }

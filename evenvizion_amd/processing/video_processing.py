@@ -98,15 +98,19 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
         if cuda:
             torch.cuda.synchronize(dev)
         feats = max(ctx.max_features, nfeatures)
+        grow = 1
         while True:
             feats *= 2
+            grow *= 2
             try:
-                big = Context(device=runtime.device_index(), max_w=max(dw, 64), max_h=max(dh, 64), max_features=feats,
-                              max_frames=chunk_frames)
+                if grow > 16:
+                    raise EvhError("giving up")
+                big = Context(device=runtime.device_index(), max_w=max(dw, 64), max_h=max(dh, 64),
+                              max_features=min(feats, 6000), max_frames=chunk_frames)
                 if "SIFT" in features:
-                    big.sift_enable(runtime.SIFT_FEATURES)
+                    big.sift_enable(min(runtime.TYPE_FEATURES_MAX, runtime.sift_features_for(dw, dh) * grow))
                 if "SURF" in features:
-                    big.surf_enable(runtime.SURF_FEATURES)
+                    big.surf_enable(min(runtime.TYPE_FEATURES_MAX, runtime.surf_features_for(dw, dh) * grow))
             except EvhError:
                 raise EvhError("frame %d..%d: more key points (ORB ties at the retainBest cut, or SIFT key points) than "
                                "the largest frame slot this device path supports" % (frame_no[0], frame_no[0] + nb - 1))

@@ -10,8 +10,20 @@ from . import _lib
 _ctx = None
 _cfg = None
 NFEATURES = 500  # cv2.ORB_create() default used by the reference (frame_processing.py:60)
-SIFT_FEATURES = 6144  # SIFT key points reserved per frame slot (SIFT_create() keeps every key point; a textured 400x224
-                      # frame has ~2 500).  The matching filter bounds a type at 7 680 key points per frame.
+SIFT_FEATURES = 6144  # SIFT key points reserved per frame slot at the reference's default resize_width (SIFT_create()
+                      # keeps every key point; a textured 400x224 frame has ~2 500)
+TYPE_FEATURES_MAX = 65535  # per frame and feature type (row indices of the pair buffers)
+
+
+def sift_features_for(w, h):
+    """SIFT key points reserved per frame slot for w x h frames: one per 14 pixels (2.6 x what textured synthetic frames
+    deliver), at least SIFT_FEATURES; a frame that delivers more is re-run on larger slots by get_homography_dict."""
+    return int(min(TYPE_FEATURES_MAX, max(SIFT_FEATURES, -(-(int(w) * int(h)) // (14 * 1024)) * 1024)))
+
+
+def surf_features_for(w, h):
+    return int(min(TYPE_FEATURES_MAX, max(SURF_FEATURES, -(-(int(w) * int(h)) // (40 * 1024)) * 1024)))
+
 
 
 def device_index():
@@ -46,9 +58,9 @@ def get_context(w, h, nframes=2, nfeatures=NFEATURES, sift=False, surf=False):
             _ctx.close()
             _ctx = _lib.Context(device=device_index(), max_w=cfg[0], max_h=cfg[1], max_features=cfg[3], max_frames=cfg[2])
         if sift and _ctx.lib.evh_sift_capacity(_ctx.h) <= 0:
-            _ctx.sift_enable(SIFT_FEATURES)
+            _ctx.sift_enable(sift_features_for(_cfg[0], _cfg[1]))
         if surf and _ctx.lib.evh_surf_capacity(_ctx.h) <= 0:
-            _ctx.surf_enable(SURF_FEATURES)
+            _ctx.surf_enable(surf_features_for(_cfg[0], _cfg[1]))
     return _ctx
 
 

@@ -263,7 +263,8 @@ int evh_compute_homography(evh_ctx* ctx, const float* h_pts, int n, const double
 enum { EVH_FEATURE_ORB = 0, EVH_FEATURE_SIFT = 1, EVH_FEATURE_SURF = 2 };
 /* Reserves the SIFT buffers of a context: max_sift_features key points per frame slot (SIFT_create() keeps every key
  * point -- 2 500 on a textured 400x224 frame), the float scale space of a group of frames.  Call once, before the entries
- * below.  A frame that delivers more is flagged: its pairs get EVH_PAIR_CAPACITY, evh_sift_count / _download fail.    */
+ * below.  A frame that delivers more is flagged: its pairs get EVH_PAIR_CAPACITY, evh_sift_count / _download fail.
+ * Up to 65 535 per frame in the *_types entries (beyond 7 680 their matching filter works in global memory).         */
 int evh_sift_enable(evh_ctx* ctx, int max_sift_features);
 int evh_sift_capacity(const evh_ctx* ctx);
 /* cv2.xfeatures2d.SIFT_create().detectAndCompute(frame, None) (frame_processing.py:62-64) on a batch of frames of

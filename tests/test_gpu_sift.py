@@ -198,6 +198,36 @@ def test_multi_type_fixed_iteration_forms_agree(monkeypatch):
         c.close()
 
 
+def test_multi_type_stream_beyond_the_lds_filter():
+    """More than 7 680 key points of one type per frame (SIFT on an 800x450 frame): the matching filter then keeps its work
+    arrays in a global scratch (k_filter<true>) instead of LDS; stream of three frames against the oracle, through the C
+    ABI and through get_homography_dict (whose SIFT slots scale with the frame area)."""
+    from evenvizion_amd import runtime
+    from evenvizion_amd.processing import get_homography_dict
+    w, h = 800, 450
+    frames, _ = S.make_stream(47, 3, w, h)
+    n = len(frames) - 1
+    Ho, so, rc = O.stream_gray_types(frames, ["SIFT", "ORB"])
+    assert rc == -1 and list(so) == [0, 0]
+    assert len(O.sift_detect(frames[1])["xy"]) > 7680          # the case this test is about
+    c = make_ctx(w, h, frames=len(frames), sift=16384)
+    try:
+        H = torch.zeros(n, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch_types(dev(frames), H, st, ["SIFT", "ORB"])
+        c.synchronize()
+        assert np.array_equal(st.cpu().numpy(), so)
+        assert np.allclose(H.cpu().numpy().reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
+    finally:
+        c.close()
+    runtime.reset()
+    d = get_homography_dict(S.SyntheticCapture([S.gray_to_bgr(f) for f in frames]), resize_width=w, features_type_list=["SIFT", "ORB"])
+    got = np.array([d[k]["H"] for k in range(2, len(frames) + 1)])
+    assert np.allclose(got, Ho, rtol=1e-9, atol=1e-12)
+    assert runtime.sift_features_for(w, h) >= 16384 and runtime.sift_features_for(400, 224) == 7168 and runtime.sift_features_for(640, 360) == 17408
+    runtime.reset()
+
+
 def test_multi_type_independent_pairs_and_bgr():
     w, h = 400, 224
     fr, _ = S.make_pair_batch(7, 2, w, h)

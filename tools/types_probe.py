@@ -14,10 +14,8 @@ for wh in (sys.argv[1:] or ["400x224"]):
     frames = np.concatenate([frames] * 4)[:nfr]
     d = torch.from_numpy(S.gray_to_bgr(frames)).cuda()
     ctx = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=nfr)
-    ctx.sift_enable(6144 if w <= 640 else 40960); ctx.surf_enable(4096 if w <= 640 else 16384)
+    ctx.sift_enable(6144 if w <= 400 else 65535); ctx.surf_enable(4096 if w <= 400 else 24576)
     for feats in (["ORB"], ["SIFT"], ["SURF"], ["SURF", "SIFT", "ORB"]):
-        if w > 640 and feats != ["ORB"] and "SIFT" in feats:
-            continue   # the matching filter bounds a type at 7 680 key points per frame
         H = torch.zeros(nfr - 1, 9, dtype=torch.float64, device='cuda'); st = torch.zeros(nfr - 1, dtype=torch.int32, device='cuda')
         ctx.stream_homography_batch_types(d, H, st, feats); ctx.synchronize()
         t = time.perf_counter()
