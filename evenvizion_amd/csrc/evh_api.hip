@@ -272,8 +272,8 @@ int detect_batch(evh_ctx* c, const uint8_t* d_frames, int nframes, int sw, int s
 int ensure_multitype(evh_ctx* c) {
   if (c->mt.cap) return EVH_SUCCESS;
   const int each = std::max(c->kcap, std::max(c->sift_cap, c->surf_cap)), cap = c->kcap + c->sift_cap + c->surf_cap;
-  if (each > 65535)
-    return evh_fail(c, EVH_ERR_CAPACITY, "multi-type pairs: at most 65535 key points per frame and type");
+  if (each > 65536)
+    return evh_fail(c, EVH_ERR_CAPACITY, "multi-type pairs: at most 65536 key points per frame and type");
   const size_t P = (size_t)c->max_frames, K = (size_t)cap;
   int rc;
 #define M_(call) if ((rc = (call)) != EVH_SUCCESS) return rc

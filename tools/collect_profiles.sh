@@ -26,5 +26,6 @@ python tools/stream_probe.py 3840x2160:4000:0 3840x2160:4000:1 > $O/stream_probe
 python tools/multi_stream_probe.py > $O/multi_stream_probe.json 2> $O/multi_stream_probe.err || true
 python tools/e2e_probe.py > $O/e2e_probe.json 2> $O/e2e_probe.err || true
 python tools/types_probe.py 400x224 > $O/types_probe.json 2> $O/types_probe.err || true
+python tools/types_probe.py 1280x720 > $O/types_probe_720p.json 2> $O/types_probe_720p.err || true
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/types_stats -o types --output-format csv -- python3 $R/tools/types_probe.py 400x224 > $O/types_stats.log 2>&1 || true)
 tail -1 $O/bench.json

@@ -166,7 +166,8 @@ for name, dst in [("bench.json", "_bench_cfg1.json"), ("bench_cfg2.json", "_benc
                   ("bench_cfg4.json", "_bench_cfg4.json"), ("bench_cfg5.json", "_bench_cfg5.json"),
                   ("bench_cfg3_forced.json", "_bench_cfg3_forced.json"), ("stream_probe.json", "_stream_probe.json"),
                   ("stream_probe_4k.json", "_stream_probe_4k.json"), ("multi_stream_probe.json", "_multi_stream_probe.json"),
-                  ("e2e_probe.json", "_e2e_probe.json"), ("types_probe.json", "_types_probe.json")]:
+                  ("e2e_probe.json", "_e2e_probe.json"), ("types_probe.json", "_types_probe.json"),
+                  ("types_probe_720p.json", "_types_probe_720p.json")]:
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 2:
         txt = open(f).read().strip()
