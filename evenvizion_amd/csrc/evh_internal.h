@@ -91,6 +91,7 @@ struct evh_ctx {
   int* d_fast_hint = nullptr;     // [2][8] per-level threshold hint (ping-pong between detect calls) + [8][256] votes + [8] zeros
   int fast_hint_idx = 0;
   double* d_lane_v = nullptr;     // fixed-iteration RANSAC: per-lane eigenvector matrices [max_frames][4][81][64] (lazy)
+  int* d_merge_ws = nullptr; size_t merge_ws_bytes = 0;     // k_merge_dup -> k_merge
   int* d_filter_ws = nullptr; size_t filter_ws_bytes = 0;   // k_filter<true>: work arrays of key-point budgets beyond the LDS form
   char* d_scan_ws = nullptr;      // fixed-iteration stream scan: state, sample table and hypothesis results (evh_ransac.hip, lazy)
   size_t scan_ws_bytes = 0;

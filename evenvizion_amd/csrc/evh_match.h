@@ -49,6 +49,7 @@ struct EvhAccArgs {
 struct EvhMergeArgs {
   const float* acc; const int* nacc; const int* accstatus; int64_t acc_stride;
   float* out; int* nout; int* status; int64_t out_stride;
+  int* work;                      // [pair][acc_stride][2]: first-of-key flag and the key's last row (set by evh_launch_merge)
 };
 
 struct evh_ctx;

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
   extern __shared__ uint32_t dyn[];
   // work arrays: claims[kcap] | mq[kcap] | mt[kcap] | keep[kcap] | lastj[kcap]
   int* claims;
-  if constexpr (GLOBAL) claims = A.work + (int64_t)blockIdx.x * 5 * A.kcap;
+  if constexpr (GLOBAL) claims = A.work + (int64_t)blockIdx.x * (5 * A.kcap + 2);      // + hdr[2]: survivors, second stage wanted
   else claims = reinterpret_cast<int*>(dyn);
   int* mq = claims + A.kcap;
   int* mt = mq + A.kcap;
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
   const float* xyq = A.xy_q + (int64_t)qs * A.xy_slot_floats;
   const float* xyt = A.xy_t + (int64_t)ts * A.xy_slot_floats;
   float* out = A.pts + (int64_t)p * A.pts_stride * 4;
+  if constexpr (GLOBAL) { if (tid == 0) claims[5 * A.kcap + 1] = 0; }     // hdr[1]: no second stage unless the survivors get that far
   if ((A.flags_arr && (A.flags_arr[qs] | A.flags_arr[ts])) != 0) {
     if (tid == 0) { A.npts[p] = 0; A.status[p] = EVH_PAIR_CAPACITY; }
     return;
@@ -307,6 +308,12 @@ __global__ __launch_bounds__(256) void k_filter(EvhFilterArgs A) {
   // coordinates of the m survivors are staged in LDS (the claim counters are dead); a thread walks them eight at a time
   // and looks at y -- a gather from global memory -- only where x matches.  (Both coordinates gathered from global memory
   // in the inner loop cost 1.4 ms on 1 000 SIFT survivors.)
+  if constexpr (GLOBAL) {
+    // thousands of survivors: the quadratic duplicate search is spread over workgroups (k_filter_dup) and k_filter_out
+    // finishes the pair; hdr[0..1] behind the five arrays carry the survivor count across the launches
+    if (tid == 0) { claims[5 * A.kcap] = m; claims[5 * A.kcap + 1] = 1; }
+    return;
+  }
   float* sx = reinterpret_cast<float*>(claims);
   for (int i = tid; i < m; i += 256) sx[i] = xyq[2 * mq[i]];
   __syncthreads();
@@ -369,11 +376,120 @@ __global__ __launch_bounds__(256) void k_accumulate(EvhAccArgs A) {
     if (base + i < A.acc_stride) dst[base + i] = src[i];
 }
 
+// second stage of k_filter<true>: remove_double_matching's duplicate search, 256 survivors per workgroup against all of
+// them (x coordinates staged through an LDS tile, y fetched only where x matches); grid (chunks, pairs)
+__global__ __launch_bounds__(256) void k_filter_dup(EvhFilterArgs A) {
+  __shared__ float s_x[2048];
+  const int p = blockIdx.y, tid = threadIdx.x;
+  int* w = A.work + (int64_t)p * (5 * A.kcap + 2);
+  const int* hdr = w + 5 * A.kcap;
+  if (!hdr[1]) return;
+  const int m = hdr[0];
+  if ((int)blockIdx.x * 256 >= m) return;
+  const int* mq = w + A.kcap;
+  int* keep = w + 3 * A.kcap;
+  int* lastj = w + 4 * A.kcap;
+  const int qs = A.q_slot0 + p * A.q_slot_step;
+  const float* xyq = A.xy_q + (int64_t)qs * A.xy_slot_floats;
+  const int i = blockIdx.x * 256 + tid;
+  const bool act = i < m;
+  const float ax = act ? xyq[2 * mq[i]] : 0.f, ay = act ? xyq[2 * mq[i] + 1] : 0.f;
+  int first = 1, last = i;
+  for (int t0 = 0; t0 < m; t0 += 2048) {
+    const int tn = min(2048, m - t0);
+    __syncthreads();
+    for (int k = tid; k < tn; k += 256) s_x[k] = xyq[2 * mq[t0 + k]];
+    __syncthreads();
+    if (act) {
+      int j = 0;
+      for (; j + 8 <= tn; j += 8) {
+        float bx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) bx[u] = s_x[j + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (bx[u] == ax && xyq[2 * mq[t0 + j + u] + 1] == ay) { if (t0 + j + u < i) first = 0; if (t0 + j + u > last) last = t0 + j + u; }
+      }
+      for (; j < tn; j++)
+        if (s_x[j] == ax && xyq[2 * mq[t0 + j] + 1] == ay) { if (t0 + j < i) first = 0; if (t0 + j > last) last = t0 + j; }
+    }
+  }
+  if (act) { keep[i] = first; lastj[i] = last; }
+}
+
+// third stage: the kept survivors in order -> the matched rows of the pair
+__global__ __launch_bounds__(256) void k_filter_out(EvhFilterArgs A) {
+  __shared__ int wave_tot[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int* w = A.work + (int64_t)p * (5 * A.kcap + 2);
+  const int* hdr = w + 5 * A.kcap;
+  if (!hdr[1]) return;                               // the first stage has already written the pair's status
+  const int m = hdr[0];
+  const int* mq = w + A.kcap; const int* mt = w + 2 * A.kcap; const int* keep = w + 3 * A.kcap; const int* lastj = w + 4 * A.kcap;
+  const int qs = A.q_slot0 + p * A.q_slot_step, ts = A.t_slot0 + p * A.t_slot_step;
+  const float* xyq = A.xy_q + (int64_t)qs * A.xy_slot_floats;
+  const float* xyt = A.xy_t + (int64_t)ts * A.xy_slot_floats;
+  float* out = A.pts + (int64_t)p * A.pts_stride * 4;
+  int u = 0;
+  for (int c0 = 0; c0 < m; c0 += 256) {
+    int i = c0 + tid;
+    bool f = i < m && keep[i];
+    int slot = block_ordered_slot(f, wave_tot, u);
+    if (f) {
+      int tq = mq[i], tt = mt[lastj[i]];
+      out[4 * slot] = xyq[2 * tq]; out[4 * slot + 1] = xyq[2 * tq + 1];
+      out[4 * slot + 2] = xyt[2 * tt]; out[4 * slot + 3] = xyt[2 * tt + 1];
+    }
+  }
+  if (tid == 0) { A.npts[p] = u; A.status[p] = EVH_PAIR_OK; }
+}
+
 // frame_processing.py:102-104: remove_double_matching over the concatenated rows of all feature types (utils.py:60-68):
 // key = exact (ax, ay), first occurrence keeps its place, the LAST occurrence gives b
+// stage 1 (grid: chunks of 256 rows x pairs): for every row whether it is the first of its (ax, ay) key and the index of
+// the key's last row -> A.work ([pair][acc_stride][2]); every workgroup walks ALL rows of its pair through an LDS tile.
+// (One workgroup per pair for the whole quadratic search took 27 ms on the 15 000 rows of a 720p SIFT + SURF + ORB pair.)
+__global__ __launch_bounds__(256) void k_merge_dup(EvhMergeArgs A) {
+  __shared__ float2 s_xy[1024];
+  const int p = blockIdx.y, tid = threadIdx.x;
+  if (A.accstatus[p] != 0) return;
+  const int m = min(A.nacc[p], (int)A.acc_stride);
+  if ((int)blockIdx.x * 256 >= m) return;
+  const float4* R = reinterpret_cast<const float4*>(A.acc + (int64_t)p * A.acc_stride * 4);
+  int* W = A.work + (int64_t)p * A.acc_stride * 2;
+  const int i = blockIdx.x * 256 + tid;
+  const bool act = i < m;
+  bool first = true; int last = i;
+  const float ax = act ? R[i].x : 0.f, ay = act ? R[i].y : 0.f;
+  for (int t0 = 0; t0 < m; t0 += 1024) {
+    const int tn = min(1024, m - t0);
+    __syncthreads();
+    for (int k = tid; k < tn; k += 256) { const float4 o = R[t0 + k]; s_xy[k] = make_float2(o.x, o.y); }
+    __syncthreads();
+    if (act) {
+      int j = 0;
+      for (; j + 8 <= tn; j += 8) {
+        float2 o[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) o[q] = s_xy[j + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (o[q].x == ax && o[q].y == ay) { if (t0 + j + q < i) first = false; if (t0 + j + q > last) last = t0 + j + q; }
+      }
+      for (; j < tn; j++) {
+        const float2 o = s_xy[j];
+        if (o.x == ax && o.y == ay) { if (t0 + j < i) first = false; if (t0 + j > last) last = t0 + j; }
+      }
+    }
+  }
+  if (act) { W[2 * i] = first ? 1 : 0; W[2 * i + 1] = last; }
+}
+
+// stage 2 (one workgroup per pair): the first rows in order, each with the b of its key's last row
 __global__ __launch_bounds__(256) void k_merge(EvhMergeArgs A) {
   __shared__ int wave_tot[4];
-  __shared__ float2 s_xy[1024];                  // a tile of the rows' (ax, ay): every thread compares its row against all of them
   const int p = blockIdx.x, tid = threadIdx.x;
   const int st = A.accstatus[p];
   if (st != 0) {
@@ -382,37 +498,14 @@ __global__ __launch_bounds__(256) void k_merge(EvhMergeArgs A) {
   }
   const int m = min(A.nacc[p], (int)A.acc_stride);
   const float4* R = reinterpret_cast<const float4*>(A.acc + (int64_t)p * A.acc_stride * 4);
+  const int* W = A.work + (int64_t)p * A.acc_stride * 2;
   float4* out = reinterpret_cast<float4*>(A.out + (int64_t)p * A.out_stride * 4);
   int u = 0;
   for (int c0 = 0; c0 < m; c0 += 256) {          // workgroup-uniform
     const int i = c0 + tid;
-    bool first = i < m; int last = i;
-    const float ax = i < m ? R[i].x : 0.f, ay = i < m ? R[i].y : 0.f;
-    // (the rows used to come one by one from global memory inside this loop: 1.25 ms on 1 900 rows)
-    for (int t0 = 0; t0 < m; t0 += 1024) {
-      const int tn = min(1024, m - t0);
-      __syncthreads();
-      for (int k = tid; k < tn; k += 256) { const float4 o = R[t0 + k]; s_xy[k] = make_float2(o.x, o.y); }
-      __syncthreads();
-      if (i < m) {
-        int j = 0;
-        for (; j + 8 <= tn; j += 8) {
-          float2 o[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) o[q] = s_xy[j + q];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < 8; q++)
-            if (o[q].x == ax && o[q].y == ay) { if (t0 + j + q < i) first = false; if (t0 + j + q > last) last = t0 + j + q; }
-        }
-        for (; j < tn; j++) {
-          const float2 o = s_xy[j];
-          if (o.x == ax && o.y == ay) { if (t0 + j < i) first = false; if (t0 + j > last) last = t0 + j; }
-        }
-      }
-    }
+    const bool first = i < m && W[2 * i] != 0;
     const int slot = block_ordered_slot(first, wave_tot, u);
-    if (first && slot < A.out_stride) { const float4 a = R[i], b = R[last]; out[slot] = make_float4(a.x, a.y, b.z, b.w); }
+    if (first && slot < A.out_stride) { const float4 a = R[i], b = R[W[2 * i + 1]]; out[slot] = make_float4(a.x, a.y, b.z, b.w); }
   }
   if (tid == 0) { A.nout[p] = u; A.status[p] = 0; }
 }
@@ -448,8 +541,17 @@ int evh_launch_accumulate(evh_ctx* c, const EvhAccArgs& A, int npairs) {
   return EVH_SUCCESS;
 }
 
-int evh_launch_merge(evh_ctx* c, const EvhMergeArgs& A, int npairs) {
+int evh_launch_merge(evh_ctx* c, const EvhMergeArgs& A_, int npairs) {
   if (npairs <= 0) return EVH_SUCCESS;
+  EvhMergeArgs A = A_;
+  const size_t need = sizeof(int) * 2 * (size_t)A.acc_stride * (size_t)npairs;
+  if (c->merge_ws_bytes < need) {
+    if (c->d_merge_ws) { EVH_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_merge_ws); c->d_merge_ws = nullptr; c->merge_ws_bytes = 0; }
+    EVH_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_merge_ws), need));
+    c->merge_ws_bytes = need;
+  }
+  A.work = c->d_merge_ws;
+  hipLaunchKernelGGL(k_merge_dup, dim3((unsigned)((A.acc_stride + 255) / 256), npairs), dim3(256), 0, c->stream, A);
   hipLaunchKernelGGL(k_merge, dim3(npairs), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;
@@ -460,7 +562,7 @@ int evh_launch_filter(evh_ctx* c, const EvhFilterArgs& A_, int npairs) {
   EvhFilterArgs A = A_;
   size_t lds = sizeof(int) * 5 * (size_t)A.kcap;
   if (lds > EVH_FILTER_LDS_MAX) {          // beyond a compute unit's LDS: the work arrays in a global scratch, grown on demand
-    const size_t need = lds * (size_t)npairs;
+    const size_t need = (lds + 2 * sizeof(int)) * (size_t)npairs;
     if (c->filter_ws_bytes < need) {
       if (c->d_filter_ws) { EVH_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_filter_ws); c->d_filter_ws = nullptr; c->filter_ws_bytes = 0; }
       EVH_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_filter_ws), need));
@@ -468,6 +570,8 @@ int evh_launch_filter(evh_ctx* c, const EvhFilterArgs& A_, int npairs) {
     }
     A.work = c->d_filter_ws;
     hipLaunchKernelGGL(k_filter<true>, dim3(npairs), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_filter_dup, dim3((A.kcap + 255) / 256, npairs), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_filter_out, dim3(npairs), dim3(256), 0, c->stream, A);
     EVH_HIP(c, hipGetLastError());
     return EVH_SUCCESS;
   }
