@@ -377,7 +377,10 @@ __device__ __forceinline__ bool kp_less(const KpRec& a, const KpRec& b) {
   return false;
 }
 __global__ __launch_bounds__(256) void k_sift_rank(SiftArgs A, int f0) {
-  __shared__ float T[256 * 6];
+  // rank = number of key points that sort before this one.  x decides almost every comparison: a tile of x values goes
+  // through LDS, the full record of the other key point is fetched only where x is equal (several orientations of one
+  // extremum).  (Full records through LDS and two full comparisons per pair: 33.6 ms per 33 frames of 25 800 key points.)
+  __shared__ float T[2048];
   const int f = f0 + blockIdx.y;
   const int n = A.nraw[f];
   if (n > A.cap || A.ncand[f] > A.cand_cap) return;        // flagged by k_sift_dedup
@@ -387,20 +390,35 @@ __global__ __launch_bounds__(256) void k_sift_rank(SiftArgs A, int f0) {
   KpRec me{0, 0, 0, 0, 0, 0};
   if (i < n) { const float* p = R + (int64_t)i * 8; me = KpRec{p[0], p[1], p[2], p[3], p[4], __float_as_int(p[5])}; }
   int rank = 0;
-  for (int t0 = 0; t0 < n; t0 += 256) {
+  auto tie = [&](int j) {                                  // equal x: the rest of the comparator, then the index
+    const float* p = R + (int64_t)j * 8;
+    const KpRec o{p[0], p[1], p[2], p[3], p[4], __float_as_int(p[5])};
+    return kp_less(o, me) || (!kp_less(me, o) && j < i);
+  };
+  for (int t0 = 0; t0 < n; t0 += 2048) {
+    const int tn = min(2048, n - t0);
     __syncthreads();
-    if (t0 + (int)threadIdx.x < n) {
-      const float* p = R + (int64_t)(t0 + threadIdx.x) * 8;
+    for (int k = threadIdx.x; k < tn; k += 256) T[k] = R[(int64_t)(t0 + k) * 8];
+    __syncthreads();
+    if (i < n) {
+      int j = 0;
+      for (; j + 8 <= tn; j += 8) {
+        float ox[8];
 #pragma unroll
-      for (int k = 0; k < 6; k++) T[threadIdx.x * 6 + k] = p[k];
-    }
-    __syncthreads();
-    const int tn = min(256, n - t0);
-    if (i < n)
-      for (int j = 0; j < tn; j++) {
-        const KpRec o{T[j * 6], T[j * 6 + 1], T[j * 6 + 2], T[j * 6 + 3], T[j * 6 + 4], __float_as_int(T[j * 6 + 5])};
-        if (kp_less(o, me) || (!kp_less(me, o) && t0 + j < i)) rank++;
+        for (int u = 0; u < 8; u++) ox[u] = T[j + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (ox[u] < me.x) rank++;
+          else if (ox[u] == me.x && tie(t0 + j + u)) rank++;
+        }
       }
+      for (; j < tn; j++) {
+        const float ox = T[j];
+        if (ox < me.x) rank++;
+        else if (ox == me.x && tie(t0 + j)) rank++;
+      }
+    }
   }
   if (i < n) {
     float* o = A.srt + ((int64_t)f * A.cap + rank) * 8;
