@@ -482,9 +482,10 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
   __shared__ float s_hist[160];
   __shared__ float s_dst[128];
   __shared__ float s_scale;
-  __shared__ int s_wtot[4];
+  __shared__ unsigned s_map[160 * 8];            // per bin: which of the chunk's 256 samples fall on it
   const int gf = blockIdx.y, f = f0 + gf, ki = blockIdx.x, tid = threadIdx.x;
   if (ki >= A.count[f]) return;
+  for (int i = tid; i < 160 * 8; i += 256) s_map[i] = 0u;      // (made visible by the first barrier of the chunk loop)
   const float* rec = A.kp + ((int64_t)f * A.cap + ki) * 8;
   const int koct = __float_as_int(rec[5]);
   int oct = koct & 255;
@@ -550,28 +551,38 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
         base = ((r0 + 1) << 16) | ((c0 + 1) << 8) | o0;
       }
     }
-    // the samples that contribute (about half of the window) are compacted IN ORDER before the bins walk them
-    const bool valid = base >= 0;
-    const unsigned long long vm = __ballot(valid);
-    const int lane = tid & 63, wv = tid >> 6;
-    if (lane == 0) s_wtot[wv] = __popcll(vm);
-    __syncthreads();
-    int off = 0, nvalid = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) { const int c = s_wtot[w]; if (w < wv) off += c; nvalid += c; }
-    if (valid) {
-      const int slot = off + __popcll(vm & ((1ull << lane) - 1ull));
-      s_base[slot] = base;
-      float* v = s_vals + slot * 8;
+    // Which samples fall on which bin: a 256-bit map per bin, set by the samples themselves with LDS atomic ORs (order-free,
+    // so the result is deterministic); a bin thread then walks the set bits of its own map in ascending order = the
+    // samples in raster order, and adds their shares.  (Every bin thread testing every contributing sample cost twelve
+    // instructions per sample and thread, 95 % of the kernel; the walk now touches only the ~5 % that hit.)
+    s_base[tid] = base;
+    {
+      float* v = s_vals + tid * 8;
 #pragma unroll
       for (int q = 0; q < 8; q++) v[q] = vv[q];
     }
+    if (base >= 0) {
+      const int rb = base >> 16, cb = (base >> 8) & 255, ob = base & 255;      // r0 + 1, c0 + 1, o0
+      const unsigned word = (unsigned)tid >> 5, bit = 1u << (tid & 31);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int r = rb + (q >> 2), c = cb + ((q >> 1) & 1), o = ob + (q & 1);
+        if (r >= 1 && r <= 4 && c >= 1 && c <= 4) atomicOr(&s_map[((r - 1) * 40 + (c - 1) * 10 + o) * 8 + word], bit);
+      }
+    }
     __syncthreads();
     if (tid < 160) {
-      for (int s = 0; s < nvalid; s++) {
-        const int b = s_base[s];
-        const unsigned dr = (unsigned)(br - (b >> 16)), dc = (unsigned)(bc - ((b >> 8) & 255)), dq = (unsigned)(bo - (b & 255));
-        if (dr < 2u && dc < 2u && dq < 2u) acc += s_vals[s * 8 + (int)(dr * 4 + dc * 2 + dq)];
+#pragma unroll
+      for (int w = 0; w < 8; w++) {
+        unsigned bits = s_map[tid * 8 + w];
+        if (bits) s_map[tid * 8 + w] = 0u;                                       // clean for the next chunk
+        while (bits) {
+          const int s = w * 32 + (__ffs((int)bits) - 1);
+          bits &= bits - 1u;
+          const int b = s_base[s];
+          const int dr = br - (b >> 16), dc = bc - ((b >> 8) & 255), dq = bo - (b & 255);
+          acc += s_vals[s * 8 + dr * 4 + dc * 2 + dq];
+        }
       }
     }
     __syncthreads();
