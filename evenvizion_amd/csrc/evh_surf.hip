@@ -200,7 +200,9 @@ __device__ __forceinline__ bool kp_greater(const SKp& a, const SKp& b) {
   return a.x < b.x;
 }
 __global__ __launch_bounds__(256) void k_surf_rank(SurfArgs A, int f0) {
-  __shared__ float T[256 * 5];
+  // rank = number of key points that sort before this one (KeypointGreater).  The response decides almost every
+  // comparison: a tile of responses goes through LDS, the full record is fetched only where they are equal.
+  __shared__ float T[2048];
   const int f = f0 + blockIdx.y;
   const int n = A.nraw[f];
   if (n > A.cap) return;
@@ -210,20 +212,35 @@ __global__ __launch_bounds__(256) void k_surf_rank(SurfArgs A, int f0) {
   SKp me{0, 0, 0, 0, 0};
   if (i < n) { const float* p = R + (int64_t)i * 8; me = SKp{p[0], p[1], p[2], p[4], __float_as_int(p[5])}; }
   int rank = 0;
-  for (int t0 = 0; t0 < n; t0 += 256) {
+  auto tie = [&](int j) {
+    const float* p = R + (int64_t)j * 8;
+    const SKp o{p[0], p[1], p[2], p[4], __float_as_int(p[5])};
+    return kp_greater(o, me) || (!kp_greater(me, o) && j < i);
+  };
+  for (int t0 = 0; t0 < n; t0 += 2048) {
+    const int tn = min(2048, n - t0);
     __syncthreads();
-    if (t0 + (int)threadIdx.x < n) {
-      const float* p = R + (int64_t)(t0 + threadIdx.x) * 8;
-      T[threadIdx.x * 5] = p[0]; T[threadIdx.x * 5 + 1] = p[1]; T[threadIdx.x * 5 + 2] = p[2]; T[threadIdx.x * 5 + 3] = p[4];
-      T[threadIdx.x * 5 + 4] = p[5];
-    }
+    for (int k = threadIdx.x; k < tn; k += 256) T[k] = R[(int64_t)(t0 + k) * 8 + 4];
     __syncthreads();
-    const int tn = min(256, n - t0);
-    if (i < n)
-      for (int j = 0; j < tn; j++) {
-        const SKp o{T[j * 5], T[j * 5 + 1], T[j * 5 + 2], T[j * 5 + 3], __float_as_int(T[j * 5 + 4])};
-        if (kp_greater(o, me) || (!kp_greater(me, o) && t0 + j < i)) rank++;
+    if (i < n) {
+      int j = 0;
+      for (; j + 8 <= tn; j += 8) {
+        float orr[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) orr[u] = T[j + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (orr[u] > me.resp) rank++;
+          else if (!(orr[u] < me.resp) && tie(t0 + j + u)) rank++;
+        }
       }
+      for (; j < tn; j++) {
+        const float orr = T[j];
+        if (orr > me.resp) rank++;
+        else if (!(orr < me.resp) && tie(t0 + j)) rank++;
+      }
+    }
   }
   if (i < n) {
     const float* p = R + (int64_t)i * 8;
