@@ -227,9 +227,14 @@ struct DogView {
 #define SR_WAVES 4
 __global__ __launch_bounds__(64 * SR_WAVES) void k_sift_refine(SiftArgs A, int f0) {
   __shared__ float s_val[SR_WAVES][SORI_N];
-  __shared__ signed char s_bin[SR_WAVES][SORI_N + 3];
+  // per wave and orientation bin: which samples of the window fall on it (bits set by the samples with LDS atomic ORs, walked
+  // in ascending order = raster order by the bin's lane; 36 lanes each testing every sample cost 6 instructions per
+  // sample and lane)
+  constexpr int SORI_W = (SORI_N + 31) / 32;
+  __shared__ unsigned s_map[SR_WAVES][36 * SORI_W];
   __shared__ float s_hist[SR_WAVES][40];
   const int gf = blockIdx.y, f = f0 + gf, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = lane; i < 36 * SORI_W; i += 64) s_map[wv][i] = 0u;
   const int ncand = min(A.ncand[f], A.cand_cap);
   const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale,
               cross_deriv_scale = img_scale * 0.25f;
@@ -317,15 +322,25 @@ __global__ __launch_bounds__(64 * SR_WAVES) void k_sift_refine(SiftArgs A, int f
         if (bin < 0) bin += 36;
         v = W * Mag;
       }
-      s_bin[wv][k] = (signed char)bin; s_val[wv][k] = v;
+      s_val[wv][k] = v;
+      if (bin >= 0) atomicOr(&s_map[wv][bin * SORI_W + (k >> 5)], 1u << (k & 31));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     float th = 0.f;
-    if (lane < 36)
-      for (int k = 0; k < len; k++)
-        if (s_bin[wv][k] == lane) th += s_val[wv][k];
+    if (lane < 36) {
+      const int nw = (len + 31) >> 5;
+      for (int w = 0; w < nw; w++) {
+        unsigned bits = s_map[wv][lane * SORI_W + w];
+        if (bits) s_map[wv][lane * SORI_W + w] = 0u;        // clean for the next candidate
+        while (bits) {
+          const int k = w * 32 + (__ffs((int)bits) - 1);
+          bits &= bits - 1u;
+          th += s_val[wv][k];
+        }
+      }
+    }
     // temphist[-2..37] with the circular padding, then the 1-4-6-4-1 smoothing
     if (lane < 36) s_hist[wv][lane + 2] = th;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(64 * SR_WAVES) void k_sift_refine(SiftArgs A, int f
     const float mag_thr = omax * 0.8f;
     const bool peak = lane < 36 && hv > hl && hv > hr && hv >= mag_thr;
     const unsigned long long pm = __ballot(peak);
-    __builtin_amdgcn_wave_barrier();                         // s_bin / s_val / s_hist are free for the next candidate
+    __builtin_amdgcn_wave_barrier();                         // s_map / s_val / s_hist are free for the next candidate
     if (pm) {
       int base = 0;
       if (lane == 0) base = atomicAdd(A.nraw + f, __popcll(pm));
