@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
   radius = min(radius, (int)sqrt(((double)cols) * cols + ((double)rows) * rows));
   cos_t /= hist_width; sin_t /= hist_width;
   const int side = 2 * radius + 1, total = side * side;
+  const float inv_side = 1.0f / (float)side;
   const int br = 1 + tid / 40, bc = 1 + (tid / 10) % 4, bo = tid % 10;
   float acc = 0.f;
   for (int k0 = 0; k0 < total; k0 += 256) {
@@ -534,7 +535,9 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
     int base = -1;
     float vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (k < total) {
-      const int i = k / side - radius, j = k % side - radius;
+      // k / side without the integer divide: exact, k + 0.5 is at least 0.5 / side away from a multiple of side (k < 2^23)
+      const int row = (int)(((float)k + 0.5f) * inv_side);
+      const int i = row - radius, j = k - row * side - radius;
       const float c_rot = (float)j * cos_t - (float)i * sin_t;
       const float r_rot = (float)j * sin_t + (float)i * cos_t;
       float rbin = r_rot + (float)(d / 2) - 0.5f;
