@@ -1078,9 +1078,9 @@ __device__ __forceinline__ double dot8(const double* a, const double* b) {
 // S.sc: 0 = S, 1 = rmax of the kept point, 2 = lambda, 3 = lc, 4 = nu, 5 = Sd, 6 = rmax of the trial point
 // evalJ(): the pass WITH the Jacobian at S.x into S.sc[0], S.sc[1], S.A8, S.v -- lm_eval by this wave alone, or the
 // four-wave form (lm_eval_mw) where the workgroup has helper waves.
-template <typename EvalJ>
+template <typename EvalJ, typename EvalN>
 __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const float* rows, int count,
-                                         unsigned long long* prof, EvalJ evalJ) {
+                                         unsigned long long* prof, EvalJ evalJ, EvalN evalN /* residuals at S.xd -> sc[5], sc[6] */) {
   const int maxIters = 10;
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   if (lane < 8) S.x[lane] = S.H[lane];
@@ -1102,7 +1102,7 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
     if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
     WSYNC();
     pe = pf_now();
-    lm_eval(S, lane, rows, count, S.xd, false, 5, 6);
+    evalN();
     pf_add(prof, PF_EVAL, pf_now() - pe);
     // trial residual -> Sd, gain ratio R; lane 0 decides, the (rare) inverse is done by the whole wave
     if (lane == 0) {
@@ -1401,15 +1401,74 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
 #undef MW_TERMBUF
 }
 
+// ---- the pass WITHOUT the Jacobian (the trial point of every LM iteration: squared norm and max |r| only) on two waves:
+// wave 1 computes the residuals of the next 64-point tile and their pair sums (rows requested a tile ahead), wave 0's
+// lane 44 adds the pair sums of the present tile in order; one workgroup barrier per tile, two pair-sum buffers.
+template <int NW, bool LANES>
+__device__ __forceinline__ void lm_eval_noj_mw(BlockLds<NW, LANES>& B, int wave, int lane, const float* rows, int count) {
+  static_assert(NW == 4 && !LANES, "helper waves: the four-wave row form only");
+  SolveLds& S = B.s;
+  double* const Pa = S.P2;
+  double* const Pb = reinterpret_cast<double*>(&B.m[0][1]);         // dead during the refinement (see lm_eval_mw)
+#define MW_P2BUF(i) (((i) & 1) ? Pb : Pa)
+  const int ntile = (count + NL - 1) / NL;
+  double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
+  if (wave == 1) { h0 = S.xd[0]; h1 = S.xd[1]; h2 = S.xd[2]; h3 = S.xd[3]; h4 = S.xd[4]; h5 = S.xd[5]; h6 = S.xd[6]; h7 = S.xd[7]; }
+  double nrm = 0, rmax = 0;
+  float4 rnext = make_float4(0, 0, 0, 0);
+  if (wave == 1 && lane < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * lane);
+  for (int n = -1; n < ntile; n++) {
+    if (wave == 1 && n + 1 < ntile) {
+      const int c0 = (n + 1) * NL, i = c0 + lane;
+      const float4 r = rnext;
+      if (i + NL < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * (i + NL));
+      double q0 = 0, q1 = 0;
+      if (i < count) {
+        const double Mx = r.x, My = r.y;
+        double ww = h6 * Mx + h7 * My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        const double xi = (h0 * Mx + h1 * My + h2) * ww;
+        const double yi = (h3 * Mx + h4 * My + h5) * ww;
+        const double rx = xi - r.z, ry = yi - r.w;
+        rmax = fmax(rmax, fabs(rx));
+        rmax = fmax(rmax, fabs(ry));
+        q0 = rx * rx; q1 = ry * ry;
+      }
+      const int cnt = min(NL, count - c0);
+      const double n0 = __shfl_down(q0, 1), n1 = __shfl_down(q1, 1);
+      double* P = MW_P2BUF(n + 1);
+      if (!(lane & 1)) {
+        if (lane + 1 < cnt) P[lane >> 1] = ((q0 + q1) + n0) + n1;
+        else if (lane < cnt) { P[NL / 2] = q0; P[NL / 2 + 1] = q1; }
+      }
+    } else if (wave == 0 && n >= 0 && lane == 44) {
+      const int cnt = min(NL, count - n * NL);
+      const double* P = MW_P2BUF(n);
+      nrm = add_in_order(nrm, P, cnt >> 1);
+      if (cnt & 1) { nrm += P[NL / 2]; nrm += P[NL / 2 + 1]; }
+    }
+    __syncthreads();
+  }
+#undef MW_P2BUF
+  if (wave == 0 && lane == 44) S.sc[5] = nrm;
+  if (wave == 1) {
+    for (int sft = 32; sft > 0; sft >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, sft));
+    if (lane == 44) S.sc[6] = rmax;
+  }
+  __syncthreads();
+}
+
 // The helper waves (1..NW-1) of a workgroup while wave 0 refines: they sleep at the workgroup barrier until wave 0 posts a
-// command in S.ib[4] (1: one lm_eval_mw pass over S.ib[5] rows of `crow`; 0: done).
+// command in S.ib[4] (1: one lm_eval_mw pass over S.ib[5] rows of `crow`; 2: one lm_eval_noj_mw pass; 0: done).
 template <int NW, bool LANES>
 __device__ __forceinline__ void lm_helper_loop(BlockLds<NW, LANES>& B, int wave, int lane, const float* crow, unsigned long long* prof) {
   if constexpr (NW == 4 && !LANES) {
     for (;;) {
       __syncthreads();
-      if (B.s.ib[4] == 0) break;
-      lm_eval_mw<NW, LANES>(B, wave, lane, crow, B.s.ib[5], prof);
+      const int cmd = B.s.ib[4];
+      if (cmd == 0) break;
+      if (cmd == 1) lm_eval_mw<NW, LANES>(B, wave, lane, crow, B.s.ib[5], prof);
+      else lm_eval_noj_mw<NW, LANES>(B, wave, lane, crow, B.s.ib[5]);
     }
   }
 }
@@ -1627,9 +1686,16 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
           __threadfence_block();
           __syncthreads();
           lm_eval_mw<NW, LANES>(B, 0, lane, crow, ni, prof);
+        }, [&]() {
+          if (ni < MW_MIN_ROWS) { lm_eval(S, lane, crow, ni, S.xd, false, 5, 6); return; }
+          if (lane == 0) { S.ib[4] = 2; S.ib[5] = ni; }
+          __threadfence_block();
+          __syncthreads();
+          lm_eval_noj_mw<NW, LANES>(B, 0, lane, crow, ni);
         });
       } else {
-        it = lm_refine(S, B.m[0][0], lane, crow, ni, prof, [&]() { lm_eval(S, lane, crow, ni, S.x, true, 0, 1); });
+        it = lm_refine(S, B.m[0][0], lane, crow, ni, prof, [&]() { lm_eval(S, lane, crow, ni, S.x, true, 0, 1); },
+                       [&]() { lm_eval(S, lane, crow, ni, S.xd, false, 5, 6); });
       }
       pf_add(prof, PF_LM, pf_now() - pf3); pf_add(prof, PF_LM_ITERS, it);
       if (info && lane == 0) info[2] = it;
