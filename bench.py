@@ -252,6 +252,10 @@ def main():
         period = U
         ctxs = [Context(device=local_rank, max_w=w, max_h=h, max_features=nfeat, max_frames=max(F, 2), stream=streams[0].cuda_stream)]
         cx = ctxs[0]
+        # the sequential scan of a chunk runs on the context's solve stream: the next chunk's detect / 2-NN kernels overlap it
+        # (its filter waits for the scan: the pair buffers are shared); --sync-solve switches that off
+        if args.kind == "stream":
+            cx.set_async_solve(not args.sync_solve)
         chunk = torch.empty((F,) + tuple(uniq.shape[1:]), dtype=torch.uint8, device=dev)
         state = torch.zeros(18, dtype=torch.float64, device=dev)
         have_state = [False]
