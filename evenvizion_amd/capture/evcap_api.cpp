@@ -21,6 +21,11 @@ struct evcap {
     PicPtr last;
     int bgr_mode = EVCAP_BGR_SWSCALE_X86;
     int width = 0, height = 0, crop_l = 0, crop_t = 0;
+    // presentation window of the edit list in media time-scale units (only when the track has exactly one edit)
+    bool honour_edits = true, have_window = false;
+    int64_t win_start = 0, win_end = 0;
+    int dropped_by_edit = 0;
+    bool started = false;
     std::string err;
 };
 
@@ -64,6 +69,20 @@ void pump(evcap* c) {
 int open_common(evcap* c, evcap** out) {
     try {
         c->track = mp4_parse(c->file);
+        // ISO/IEC 14496-12 8.6.6: an edit maps [media_time, media_time + segment_duration) onto the presentation; samples
+        // whose composition time lies outside it are decoded (they may be references) but not presented.  FFmpeg's mov
+        // demuxer, which cv2.VideoCapture reads through, does the same (it flags such samples "discard"), and that is why
+        // the reference's run of test_video.mp4 saw 121 of its 122 samples: the last one is composed 507 ticks after the
+        // end of the only edit.  segment_duration is in movie time-scale units; rounded to nearest like av_rescale.
+        if (c->track.edits.size() == 1 && c->track.edits[0].media_time >= 0 && c->track.edits[0].segment_duration > 0 &&
+            c->track.movie_timescale > 0) {
+            const Mp4Track::Edit& e = c->track.edits[0];
+            const unsigned __int128 num = (unsigned __int128)e.segment_duration * c->track.timescale;
+            const uint64_t dur = (uint64_t)((num + c->track.movie_timescale / 2) / c->track.movie_timescale);
+            c->have_window = true;
+            c->win_start = e.media_time;
+            c->win_end = e.media_time + (int64_t)dur;
+        }
         for (auto& s : c->track.sps) c->dec.decode_nal(s.data(), s.size());
         for (auto& p : c->track.pps) c->dec.decode_nal(p.data(), p.size());
         // decode ahead to the first picture so that the geometry is known (in-band parameter sets may override avcC)
@@ -186,6 +205,13 @@ int evcap_info(evcap* c, int* width, int* height, int* frame_count, double* fps)
     return EVCAP_OK;
 }
 
+int evcap_set_honour_edit_list(evcap* c, int on) {
+    if (!c) return EVCAP_ERR_INVALID;
+    if (c->started) return EVCAP_ERR_INVALID;  // only before the first read
+    c->honour_edits = on != 0;
+    return EVCAP_OK;
+}
+
 int evcap_set_bgr_mode(evcap* c, int mode) {
     if (!c || (mode != EVCAP_BGR_SWSCALE_X86 && mode != EVCAP_BGR_SWSCALE_C)) return EVCAP_ERR_INVALID;
     c->bgr_mode = mode;
@@ -193,19 +219,30 @@ int evcap_set_bgr_mode(evcap* c, int mode) {
 }
 
 static int next_picture(evcap* c, PicPtr& p) {
-    try {
-        pump(c);
-    } catch (const std::exception& e) {
-        c->err = e.what();
-        c->flushed = true;
-        c->ready.clear();
-        return classify(c->err);
+    for (;;) {
+        try {
+            pump(c);
+        } catch (const std::exception& e) {
+            c->err = e.what();
+            c->flushed = true;
+            c->ready.clear();
+            return classify(c->err);
+        }
+        if (c->ready.empty()) return EVCAP_EOF;
+        p = c->ready.front();
+        c->ready.pop_front();
+        // one picture per sample: Picture::id counts pictures in decoding order = sample index
+        if (c->honour_edits && c->have_window && (size_t)p->id < c->track.samples.size()) {
+            const int64_t cts = c->track.samples[(size_t)p->id].pts;
+            if (cts < c->win_start || cts >= c->win_end) {
+                ++c->dropped_by_edit;
+                continue;
+            }
+        }
+        c->last = p;
+        c->started = true;
+        return EVCAP_OK;
     }
-    if (c->ready.empty()) return EVCAP_EOF;
-    p = c->ready.front();
-    c->ready.pop_front();
-    c->last = p;
-    return EVCAP_OK;
 }
 
 int evcap_read_bgr(evcap* c, uint8_t* dst, int64_t stride) {

@@ -48,6 +48,10 @@ void evcap_close(evcap* c);
 int evcap_info(evcap* c, int* width, int* height, int* frame_count, double* fps);
 
 int evcap_set_bgr_mode(evcap* c, int mode);
+/* Edit lists (ISO/IEC 14496-12 8.6.6): by default a sample whose composition time lies outside the track's single edit is
+ * decoded but not presented -- what FFmpeg's mov demuxer under cv2.VideoCapture does, and the reason the reference's own
+ * run of test_video.mp4 holds 120 pairs for 122 samples.  on = 0 presents every decoded picture.  Call before reading. */
+int evcap_set_honour_edit_list(evcap* c, int on);
 
 /* capture.read() -- video_processing.py:58,70.  Writes the next frame in presentation order as 8-bit BGR, rows of
  * width*3 bytes at `stride`.  Returns EVCAP_OK, EVCAP_EOF or an error. */

@@ -47,6 +47,11 @@ int64_t evo_orb_pyramid(const uint8_t* gray, int w, int h, uint8_t* out);
 int evo_fast_nms(const uint8_t* img, int w, int h, int threshold, int* xs, int* ys, int* scores, int cap);
 void evo_fast_score_map(const uint8_t* img, int w, int h, int threshold, uint8_t* out);
 /* candidates after border filter + retainBest(2*quota) for one level, row-major; returns count */
+/* order (and, with ties at the cut, the set) KeyPointsFilter::retainBest leaves the key points in: 1 = OpenCV 3.4.2's call on
+ * libstdc++'s nth_element/partition (default, pinned by the reference's golden), 0 = all ties kept in row-major order, 2..4 = the
+ * other combinations of OpenCV's nth index and libstdc++'s pivot rule (evz_orb.cpp) */
+void evo_set_orb_order(int mode);
+int evo_get_orb_order(void);
 int evo_orb_level_candidates(const uint8_t* img, int w, int h, int quota, int* xs, int* ys, int* scores, int cap);
 /* 7x7/sigma=2 8-bit Gaussian blur with reflect-101 borders (K6 first half) */
 void evo_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst);
@@ -80,6 +85,11 @@ int evo_surf_detect(const uint8_t* gray, int w, int h, float* xy, float* desc, f
 /* one stream with a LIST of feature types (0 = ORB, 1 = SIFT, 2 = SURF), frame_processing.py:91-104 + video_processing.py:67-105 */
 int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types, int ntypes,
                           double* H, int* status);
+/* force_max: all RANSACs run 2000 iterations; Hsup_forced (NULL or [F-1][9]): the plane pair k is solved in; npts (NULL or [F-1]) */
+int evo_stream_gray_types_ex(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types, int ntypes,
+                             int force_max, const double* Hsup_forced, double* H, int* status, int* npts);
+int evo_match_static_f32_ex(const float* xy_a, const float* desc_a, int na, const float* xy_b, const float* desc_b, int nb,
+                            int dim, int force_max, float* oa, float* ob, int* out_n);
 
 /* ---- K7 + glue: matching (matching.py:75-129, 166-239; utils.py:41-68) ---- */
 void evo_knn2_l2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, uint32_t* d2);

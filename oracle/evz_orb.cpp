@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -315,20 +316,100 @@ void fast_nms(const uint8_t* img, int w, int h, int thr, std::vector<Corner>& ou
     }
 }
 
-/* KeyPointsFilter::retainBest semantics as a set: keep everything whose response is >= the n-th largest */
+/* ---- KeyPointsFilter::retainBest (features2d/src/keypoint.cpp), including the ORDER it leaves the survivors in ----
+ * OpenCV:  std::nth_element(begin, begin + nth, end, response-greater); amb = kp[n-1].response;
+ *          new_end = std::partition(begin + n, end, response >= amb); resize.
+ * Both calls permute the vector, and everything downstream (match order -> RANSAC sample order) depends on that permutation,
+ * so the oracle runs the same two algorithms of libstdc++ on the same sequence.  nth_element is libstdc++'s introselect;
+ * two generations of its pivot rule exist (GCC < 4.8.2 / 4.9: median of first, mid, last-1 moved to first; later: median of
+ * first+1, mid, last-1), and two versions of OpenCV's call (nth = n in 3.x, n - 1 after the 2018 fix).  g_order_mode:
+ *   0  set semantics, row-major order kept (rounds 1-3 of this repository)
+ *   1  nth = n,     current libstdc++        2  nth = n - 1, current libstdc++
+ *   3  nth = n,     old pivot rule           4  nth = n - 1, old pivot rule
+ * Mode 1 is the one the reference's own run agrees with (tests/test_capture_golden.py: 109 of 120 pairs of
+ * dict_with_homography_matrix.json within 1e-3 against 15 in mode 0, 78 in mode 2, 18 and 23 in modes 3 and 4) and is the default;
+ * evo_set_orb_order() / the environment variable EVO_ORB_ORDER select another. */
+int g_order_mode = -1;
+int order_mode() {
+  if (g_order_mode < 0) { const char* e = getenv("EVO_ORB_ORDER"); g_order_mode = e ? atoi(e) : 1; }
+  return g_order_mode;
+}
+template <class It, class C> void old_move_median_first(It a, It b, It c, C comp) {
+  if (comp(*a, *b)) { if (comp(*b, *c)) std::iter_swap(a, b); else if (comp(*a, *c)) std::iter_swap(a, c); }
+  else if (comp(*a, *c)) return;
+  else if (comp(*b, *c)) std::iter_swap(a, c);
+  else std::iter_swap(a, b);
+}
+template <class It, class C> void new_move_median_to_first(It r, It a, It b, It c, C comp) {
+  if (comp(*a, *b)) { if (comp(*b, *c)) std::iter_swap(r, b); else if (comp(*a, *c)) std::iter_swap(r, c); else std::iter_swap(r, a); }
+  else if (comp(*a, *c)) std::iter_swap(r, a);
+  else if (comp(*b, *c)) std::iter_swap(r, c);
+  else std::iter_swap(r, b);
+}
+template <class It, class C> It unguarded_partition(It first, It last, It pivot, C comp) {
+  for (;;) {
+    while (comp(*first, *pivot)) ++first;
+    --last;
+    while (comp(*pivot, *last)) --last;
+    if (!(first < last)) return first;
+    std::iter_swap(first, last);
+    ++first;
+  }
+}
+template <class It, class C> void insertion_sort(It first, It last, C comp) {
+  if (first == last) return;
+  for (It i = first + 1; i != last; ++i) {
+    auto val = *i;
+    if (comp(val, *first)) { std::move_backward(first, i, i + 1); *first = val; }
+    else { It l = i, nx = i; --nx; while (comp(val, *nx)) { *l = *nx; l = nx; --nx; } *l = val; }
+  }
+}
+/* libstdc++ __introselect; old_rule selects the pre-4.9 pivot.  The depth-limit fall-back (heap select) is reached only on
+ * adversarial input; it is reported instead of emulated. */
+template <class It, class C> bool introselect(It first, It nth, It last, C comp, bool old_rule) {
+  if (first == last || nth == last) return true;
+  long n = last - first; int lg = 0; while (n > 1) { n >>= 1; ++lg; }
+  int depth = 2 * lg;
+  while (last - first > 3) {
+    if (depth == 0) return false;
+    --depth;
+    It mid = first + (last - first) / 2;
+    if (old_rule) old_move_median_first(first, mid, last - 1, comp);
+    else new_move_median_to_first(first, first + 1, mid, last - 1, comp);
+    It cut = unguarded_partition(first + 1, last, first, comp);
+    if (cut <= nth) first = cut; else last = cut;
+  }
+  insertion_sort(first, last, comp);
+  return true;
+}
 template <class T, class F>
 void retain_best(std::vector<T>& v, int n, F resp) {
   if (n < 0 || (int)v.size() <= n) return;
   if (n == 0) { v.clear(); return; }
-  std::vector<float> r(v.size());
-  for (size_t i = 0; i < v.size(); i++) r[i] = resp(v[i]);
-  std::vector<float> s = r;
-  std::nth_element(s.begin(), s.begin() + (n - 1), s.end(), std::greater<float>());
-  float cut = s[n - 1];
-  std::vector<T> keep;
-  for (size_t i = 0; i < v.size(); i++)
-    if (r[i] >= cut) keep.push_back(v[i]);  // stable: row-major order survives
-  v.swap(keep);
+  const int mode = order_mode();
+  if (mode == 0) {
+    std::vector<float> r(v.size());
+    for (size_t i = 0; i < v.size(); i++) r[i] = resp(v[i]);
+    std::vector<float> s = r;
+    std::nth_element(s.begin(), s.begin() + (n - 1), s.end(), std::greater<float>());
+    float cut = s[n - 1];
+    std::vector<T> keep;
+    for (size_t i = 0; i < v.size(); i++)
+      if (r[i] >= cut) keep.push_back(v[i]);  // stable: row-major order survives
+    v.swap(keep);
+    return;
+  }
+  auto greater = [&](const T& a, const T& b) { return resp(a) > resp(b); };
+  const int nth = (mode == 1 || mode == 3) ? n : n - 1;
+  std::vector<T> backup = v;
+  if (!introselect(v.begin(), v.begin() + nth, v.end(), greater, mode >= 3)) {
+    if (mode >= 3) fprintf(stderr, "evz_orb: introselect depth limit reached (old-rule heap fall-back not emulated)\n");
+    v = backup;
+    std::nth_element(v.begin(), v.begin() + nth, v.end(), greater);
+  }
+  const float amb = resp(v[n - 1]);
+  auto ne = std::partition(v.begin() + n, v.end(), [&](const T& k) { return resp(k) >= amb; });
+  v.resize(ne - v.begin());
 }
 
 void level_candidates(const uint8_t* img, int w, int h, int quota, std::vector<Corner>& c) {
@@ -445,6 +526,9 @@ extern "C" void evo_sincos(double x, double* so, double* co) {
   }
   *so = s; *co = c;
 }
+
+extern "C" void evo_set_orb_order(int mode) { g_order_mode = (mode >= 0 && mode <= 4) ? mode : 1; }
+extern "C" int evo_get_orb_order(void) { return order_mode(); }
 
 extern "C" int evo_fast_nms(const uint8_t* img, int w, int h, int thr, int* xs, int* ys, int* scores, int cap) {
   std::vector<Corner> c;

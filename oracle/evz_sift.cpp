@@ -570,8 +570,8 @@ extern "C" int evo_ratio_unique_f32(const int32_t* idx, const float* dist, int n
 }
 
 /* KeyPoints.match_static_kps (matching.py:131-163) on float descriptors */
-extern "C" int evo_match_static_f32(const float* xy_a, const float* desc_a, int na, const float* xy_b, const float* desc_b, int nb,
-                                    int dim, float* oa, float* ob, int* out_n) {
+extern "C" int evo_match_static_f32_ex(const float* xy_a, const float* desc_a, int na, const float* xy_b, const float* desc_b, int nb,
+                                       int dim, int force_max, float* oa, float* ob, int* out_n) {
   *out_n = 0;
   if (na == 0 || nb == 0) return EVO_NO_DESCRIPTORS;
   std::vector<int32_t> idx(2 * (size_t)na), mq(na), mt(na);
@@ -587,9 +587,13 @@ extern "C" int evo_match_static_f32(const float* xy_a, const float* desc_a, int 
   const int u = evo_remove_double(pa.data(), pb.data(), m, ua.data(), ub.data());
   double H[9];
   std::vector<uint8_t> mask(u);
-  if (!evo_find_homography(ua.data(), ub.data(), u, 3.0, 2000, 0.995, H, mask.data(), nullptr)) return EVO_NO_PROVISIONAL_H;
+  if (!evo_find_homography_ex(ua.data(), ub.data(), u, 3.0, 2000, 0.995, force_max, H, mask.data(), nullptr)) return EVO_NO_PROVISIONAL_H;
   *out_n = evo_static_filter(H, ua.data(), ub.data(), u, oa, ob);
   return EVO_OK;
+}
+extern "C" int evo_match_static_f32(const float* xy_a, const float* desc_a, int na, const float* xy_b, const float* desc_b, int nb,
+                                    int dim, float* oa, float* ob, int* out_n) {
+  return evo_match_static_f32_ex(xy_a, desc_a, na, xy_b, desc_b, nb, dim, 0, oa, ob, out_n);
 }
 
 namespace {
@@ -618,8 +622,12 @@ void detect_type(const uint8_t* gray, int w, int h, int nfeatures, int type, TFe
 
 /* one stream, a list of feature types (0 = ORB, 1 = SIFT, 2 = SURF) processed in list order; H [F-1][9], status [F-1]; returns the
  * index of a failing FIRST pair or -1 (as evo_stream_gray) */
-extern "C" int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types,
-                                     int ntypes, double* H, int* status) {
+/* _ex: force_max = every RANSAC runs its 2000 iterations (BASELINE configs[2]); Hsup_forced (or NULL) [F-1][9] replaces the
+ * running superposition: pair k (k >= 1, 0-based) is solved in the plane Hsup_forced[k-1] instead of the plane the stream itself
+ * accumulated -- used to compare pair by pair with a recorded reference run without the drift of earlier pairs; npts (or NULL)
+ * receives the number of point pairs handed to the final RANSAC per pair. */
+extern "C" int evo_stream_gray_types_ex(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types,
+                                        int ntypes, int force_max, const double* Hsup_forced, double* H, int* status, int* npts) {
   const size_t fs = (size_t)w * h;
   std::vector<TFeat> prev(ntypes), cur(ntypes);
   for (int t = 0; t < ntypes; t++) detect_type(frames, w, h, nfeatures, types[t], prev[t]);
@@ -634,15 +642,18 @@ extern "C" int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, 
       const TFeat& a = cur[t]; const TFeat& b = prev[t];
       std::vector<float> oa(2 * (size_t)std::max(a.n, 1)), ob(2 * (size_t)std::max(a.n, 1));
       int n = 0;
-      if (types[t] != 0) st = evo_match_static_f32(a.xy.data(), a.df.data(), a.n, b.xy.data(), b.df.data(), b.n, 128, oa.data(), ob.data(), &n);
-      else st = evo_match_static(a.xy.data(), a.d8.data(), a.n, b.xy.data(), b.d8.data(), b.n, oa.data(), ob.data(), &n);
+      if (types[t] != 0) st = evo_match_static_f32_ex(a.xy.data(), a.df.data(), a.n, b.xy.data(), b.df.data(), b.n, 128, force_max, oa.data(), ob.data(), &n);
+      else st = evo_match_static_ex(a.xy.data(), a.d8.data(), a.n, b.xy.data(), b.d8.data(), b.n, force_max, oa.data(), ob.data(), &n);
       if (st == EVO_OK) { alla.insert(alla.end(), oa.begin(), oa.begin() + 2 * n); allb.insert(allb.end(), ob.begin(), ob.begin() + 2 * n); }
     }
+    if (npts) npts[k - 1] = 0;
     if (st == EVO_OK) {
       const int n = (int)alla.size() / 2;
       std::vector<float> ua(alla.size() + 2), ub(alla.size() + 2);
       const int u = evo_remove_double(alla.data(), allb.data(), n, ua.data(), ub.data());
-      st = evo_compute_homography(ua.data(), ub.data(), u, first ? nullptr : Hsup, Hk);
+      if (npts) npts[k - 1] = u;
+      if (Hsup_forced && k >= 2) memcpy(Hsup, Hsup_forced + 9 * (size_t)(k - 2), sizeof(Hsup));
+      st = evo_compute_homography_ex(ua.data(), ub.data(), u, first ? nullptr : Hsup, force_max, Hk);
     }
     status[k - 1] = st;
     if (st != EVO_OK) {
@@ -657,4 +668,9 @@ extern "C" int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, 
     std::swap(prev, cur);
   }
   return -1;
+}
+
+extern "C" int evo_stream_gray_types(const uint8_t* frames, int nframes, int w, int h, int nfeatures, const int* types,
+                                     int ntypes, double* H, int* status) {
+  return evo_stream_gray_types_ex(frames, nframes, w, h, nfeatures, types, ntypes, 0, nullptr, H, status, nullptr);
 }

@@ -37,6 +37,15 @@ def lib():
     return _lib
 
 
+def set_orb_order(mode):
+    """1 (default): key points leave retainBest in the order OpenCV 3.4.2 + libstdc++ leave them; 0: row-major, all ties kept."""
+    lib().evo_set_orb_order(int(mode))
+
+
+def get_orb_order():
+    return int(lib().evo_get_orb_order())
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -351,13 +360,22 @@ def match_static_f32(xy_a, desc_a, xy_b, desc_b):
 FEATURE_CODES = {"ORB": 0, "SIFT": 1, "SURF": 2}
 
 
-def stream_gray_types(frames, features, nfeatures=500):
-    """frames u8[F,h,w], features e.g. ["SIFT", "ORB"] -> (H f64[F-1,3,3], status i32[F-1], failed_first_pair_index or -1)"""
+def stream_gray_types(frames, features, nfeatures=500, force_max_iters=False, Hsup_forced=None, return_npts=False):
+    """frames u8[F,h,w], features e.g. ["SIFT", "ORB"] -> (H f64[F-1,3,3], status i32[F-1], failed_first_pair_index or -1).
+    Hsup_forced f64[F-1,3,3]: pair k (0-based, k >= 1) is solved in the plane Hsup_forced[k-1] instead of the plane the stream
+    accumulated itself (pair-by-pair comparison with a recorded run); return_npts adds the RANSAC input sizes."""
     frames = _u8(frames)
     nf, h, w = frames.shape
     t = np.ascontiguousarray([FEATURE_CODES[f] for f in features], np.int32)
-    H = np.zeros((nf - 1, 9), np.float64); st = np.zeros(nf - 1, np.int32)
-    rc = lib().evo_stream_gray_types(_p(frames), nf, w, h, nfeatures, _p(t), len(t), _p(H), _p(st))
+    H = np.zeros((nf - 1, 9), np.float64); st = np.zeros(nf - 1, np.int32); npts = np.zeros(nf - 1, np.int32)
+    hs = None
+    if Hsup_forced is not None:
+        hs = np.ascontiguousarray(Hsup_forced, np.float64).reshape(-1, 9)
+        assert hs.shape[0] >= nf - 1
+    rc = lib().evo_stream_gray_types_ex(_p(frames), nf, w, h, nfeatures, _p(t), len(t), 1 if force_max_iters else 0,
+                                        _p(hs) if hs is not None else None, _p(H), _p(st), _p(npts))
+    if return_npts:
+        return H.reshape(-1, 3, 3), st, rc, npts
     return H.reshape(-1, 3, 3), st, rc
 
 
