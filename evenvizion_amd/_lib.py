@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("EVHIP_LIBRARY") or os.path.join(_HERE, "libevhip.so")
 EVH_SUCCESS = 0
 PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_FEW_MATCHES, PAIR_NO_PROVISIONAL_H, PAIR_LOW_INLIER_RATIO, PAIR_NO_FINAL_H, \
     PAIR_CAPACITY = range(7)
+ORDER_CANONICAL, ORDER_OPENCV = 0, 1
 MODE_INDEPENDENT_PAIRS, MODE_STREAM = 0, 1
 
 # every symbol include/evhip.h declares, with its ctypes signature
@@ -41,6 +42,8 @@ SIGNATURES = {
     "evh_orb_detect_batch_resized": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i]),
     "evh_stream_homography_batch_resized": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "evh_set_fast_lift": (_i, [_vp, _i]),
+    "evh_set_keypoint_order": (_i, [_vp, _i]),
+    "evh_get_keypoint_order": (_i, [_vp]),
     "evh_set_fast_share": (_i, [_vp, _i]),
     "evh_set_fast_hint": (_i, [_vp, _i]),
     "evh_orb_count": (_i, [_vp, _i]),
@@ -204,6 +207,14 @@ class Context:
 
     def set_fast_lift(self, on=True):
         self._check(self.lib.evh_set_fast_lift(self.h, int(bool(on))))
+
+    def set_keypoint_order(self, mode):
+        """ORDER_OPENCV (default): key points leave retainBest in the order (and set) OpenCV 3.4.2 on libstdc++ leaves them --
+        the reference's; ORDER_CANONICAL: all ties kept, (level, y, x) order (faster: FAST threshold lifting applies)."""
+        self._check(self.lib.evh_set_keypoint_order(self.h, int(mode)))
+
+    def get_keypoint_order(self):
+        return int(self.lib.evh_get_keypoint_order(self.h))
 
     def set_fast_hint(self, on=True):
         self._check(self.lib.evh_set_fast_hint(self.h, int(bool(on))))

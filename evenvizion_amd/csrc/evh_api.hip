@@ -454,6 +454,15 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_fast_thr, F * EVH_NLEVELS));
   A_(dalloc(c, &c->d_fast_hist, F * EVH_NLEVELS * 256));
   A_(dalloc(c, &c->d_fast_redo, F * EVH_NLEVELS + 1));
+  {
+    int64_t mw = 0;
+    for (int l = 0; l < EVH_NLEVELS; l++) mw += (int64_t)((gmax.lv[l].w + 31) / 32) * gmax.lv[l].h;
+    c->cv_mask_frame_words = mw + 64;
+  }
+  A_(dalloc(c, &c->d_cv_seq, F * (size_t)gmax.cand_frame_entries));
+  A_(dalloc(c, &c->d_cv_lpos, F * (size_t)gmax.cand_frame_entries));
+  A_(dalloc(c, &c->d_cv_rpos, F * (size_t)gmax.cand_frame_entries));
+  A_(dalloc(c, &c->d_cv_mask, F * 2 * (size_t)c->cv_mask_frame_words));
   A_(dalloc(c, &c->d_fast_hint, 16 + 8 * 256 + 8));
   if (hipMemset(c->d_fast_hint, 0, sizeof(int) * (16 + 8 * 256 + 8)) != hipSuccess) {
     c->err = "hipMemset(d_fast_hint) failed";
@@ -485,7 +494,7 @@ void evh_destroy(evh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
-                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_cv_seq, c->d_cv_lpos, c->d_cv_rpos, c->d_cv_mask, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch, c->d_scan_ws, c->d_filter_ws, c->d_merge_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   evh_sift_free(c);
@@ -511,6 +520,14 @@ int evh_set_fast_lift(evh_ctx* c, int on) {
   c->fast_lift = on != 0;
   return EVH_SUCCESS;
 }
+
+int evh_set_keypoint_order(evh_ctx* c, int mode) {
+  if (!c || (mode != EVH_ORDER_CANONICAL && mode != EVH_ORDER_OPENCV)) return EVH_ERR_INVALID;
+  c->order_mode = mode;
+  return EVH_SUCCESS;
+}
+
+int evh_get_keypoint_order(const evh_ctx* c) { return c ? c->order_mode : EVH_ERR_INVALID; }
 
 int evh_set_fast_hint(evh_ctx* c, int on) {
   if (!c) return EVH_ERR_INVALID;
@@ -673,6 +690,7 @@ int evh_orb_count(evh_ctx* c, int frame) {
   EVH_HIP(c, hipMemcpyAsync(&n, c->d_kp_count + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   EVH_HIP(c, hipMemcpyAsync(&fl, c->d_frame_flags + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   EVH_HIP(c, hipStreamSynchronize(c->stream));
+  if (fl & 2) return evh_fail(c, EVH_ERR_CAPACITY, "key-point selection: nth_element's depth limit was reached for this frame (heap-select fall-back)");
   if (fl) return evh_fail(c, EVH_ERR_CAPACITY, "a fixed-capacity keypoint list overflowed for this frame");
   return n;
 }

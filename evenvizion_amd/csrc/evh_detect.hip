@@ -1405,6 +1405,347 @@ __global__ __launch_bounds__(256) void k_pack(SelectArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K4, reference order (EVH_ORDER_OPENCV, the default).  KeyPointsFilter::retainBest (features2d/src/keypoint.cpp) is
+//     std::nth_element(begin, begin + n, end, response-greater); amb = kp[n - 1].response;
+//     new_end = std::partition(begin + n, end, response >= amb); resize(new_end - begin)
+// and both calls PERMUTE the vector: the order ORB hands its key points over in -- hence the order of the matches, of the
+// rows given to RANSAC, hence which minimal samples its random generator draws -- is the order libstdc++'s introselect and
+// partition leave behind, and with ties at the cut even the surviving SET depends on it (position n - 1 holds an arbitrary
+// member of the best n).  The reference's own recorded run agrees with this order and with no other
+// (tests/test_capture_golden.py), so the order is part of the operator.  k_select_cv runs the same algorithms on the same
+// sequence (FAST corners of a level in row-major order), with every pass over the data done by the whole workgroup:
+//   * Hoare's unguarded partition = pair the k-th element from the left that is not "before" the pivot with the k-th from
+//     the right that is not "after" it while the former lies left of the latter; the pairs are independent, so the two
+//     stopper lists are built by a scan, the number of pairs by a search, the swaps in parallel; the cut follows from the
+//     first unpaired stoppers.  std::partition is the same with a predicate.
+//   * the row-major sequence comes from a bit plane of the corners: rank = set bits before the corner.
+// What stays sequential is what libstdc++ does per round in O(1): the median-of-three pivot and the final insertion sort.
+struct SelCvArgs {
+  SelectArgs s;
+  unsigned long long* seq;   // [nframes][cand_frame_entries]  key << 32 | packed candidate
+  uint32_t* lpos;            // [nframes][cand_frame_entries]  left-stopper positions, ascending
+  uint32_t* rpos;            // [nframes][cand_frame_entries]  right-stopper positions, ascending
+  uint32_t* mask;            // [nframes][2 * mask_frame_words] corner bit plane, then its running popcount
+  int64_t mask_frame_words;
+  int mask_off[EVH_NLEVELS];
+  int heap_cap;              // entries of the dynamic LDS heap (>= 2 * largest quota + 1)
+};
+
+struct CvLds {
+  int wsumL[4], wsumR[4];
+  int bc[8];
+  unsigned long long tmp[4];
+};
+
+#define CV_NOPOS 0x7FFFFFFF
+
+// exclusive prefix of (a, b) over the 256 threads of the workgroup; totals come back in ta / tb.  Two barriers.
+__device__ __forceinline__ void cv_scan2(CvLds& S, int a, int b, int& ea, int& eb, int& ta, int& tb) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ua = __shfl_up(ia, o), ub = __shfl_up(ib, o);
+    if (lane >= o) { ia += ua; ib += ub; }
+  }
+  if (lane == 63) { S.wsumL[wv] = ia; S.wsumR[wv] = ib; }
+  __syncthreads();
+  int ba = 0, bb = 0;
+  for (int w = 0; w < wv; w++) { ba += S.wsumL[w]; bb += S.wsumR[w]; }
+  ta = S.wsumL[0] + S.wsumL[1] + S.wsumL[2] + S.wsumL[3];
+  tb = S.wsumR[0] + S.wsumR[1] + S.wsumR[2] + S.wsumR[3];
+  ea = ba + ia - a;
+  eb = bb + ib - b;
+  __syncthreads();
+}
+
+// Partition pass over a[lo, hi).  MODE 0: Hoare around the pivot key p (left stoppers key <= p, right stoppers key >= p),
+// returns the cut.  MODE 1: std::partition with the predicate key >= p (left stoppers !pred, right stoppers pred), returns
+// the position of the first element of the false group.
+template <int MODE>
+__device__ int cv_partition(unsigned long long* a, int lo, int hi, uint32_t p, uint32_t* lpos, uint32_t* rpos, CvLds& S) {
+  const int tid = threadIdx.x;
+  int cntL = 0, cntR = 0;
+  for (int base = lo; base < hi; base += 1024) {
+    const int i0 = base + 4 * tid;
+    uint32_t fl = 0, fr = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (i0 + e < hi) {
+        const uint32_t key = (uint32_t)(a[i0 + e] >> 32);
+        const bool le = MODE == 0 ? key <= p : key < p;
+        const bool ge = key >= p;
+        fl |= (le ? 1u : 0u) << e;
+        fr |= (ge ? 1u : 0u) << e;
+      }
+    }
+    int el, er, tl, tr;
+    cv_scan2(S, __popc(fl), __popc(fr), el, er, tl, tr);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if ((fl >> e) & 1u) lpos[cntL + el++] = (uint32_t)(i0 + e);
+      if ((fr >> e) & 1u) rpos[cntR + er++] = (uint32_t)(i0 + e);
+    }
+    cntL += tl;
+    cntR += tr;
+  }
+  __syncthreads();   // lists complete
+  // number of pairs: the largest m with L[k] < R[k] for all k < m (monotone), by 256-way search; R[k] = rpos[cntR - 1 - k]
+  const int K = min(cntL, cntR);
+  int lo_k = 0, hi_k = K;   // invariant: pairs [0, lo_k) swap, pairs [hi_k, K) do not
+  while (hi_k > lo_k) {
+    const int span = hi_k - lo_k;
+    const int step = (span + 255) / 256;
+    const int k = lo_k + tid * step;
+    const bool ok = k < hi_k && lpos[k] < rpos[cntR - 1 - k];
+    const unsigned long long bal = __ballot(ok);
+    if ((tid & 63) == 0) S.bc[tid >> 6] = __popcll(bal);
+    __syncthreads();
+    const int good = S.bc[0] + S.bc[1] + S.bc[2] + S.bc[3];   // probes are monotone: the first `good` probes hold
+    __syncthreads();
+    if (good == 0) { hi_k = lo_k; break; }
+    const int last_good = lo_k + (good - 1) * step;
+    lo_k = last_good + 1;
+    hi_k = min(hi_k, last_good + step);
+  }
+  const int m = lo_k;
+  for (int k = tid; k < m; k += 256) {
+    const uint32_t i = lpos[k], j = rpos[cntR - 1 - k];
+    const unsigned long long t = a[i];
+    a[i] = a[j];
+    a[j] = t;
+  }
+  int ret;
+  if (MODE == 0) {
+    const int Lm = m < cntL ? (int)lpos[m] : CV_NOPOS;
+    const int Rm1 = m > 0 ? (int)rpos[cntR - m] : CV_NOPOS;
+    ret = min(Lm, Rm1);
+  } else {
+    ret = lo + cntR;
+  }
+  __syncthreads();   // swaps visible, lists free
+  return ret;
+}
+
+__device__ __forceinline__ bool cv_gt(unsigned long long x, unsigned long long y) { return (uint32_t)(x >> 32) > (uint32_t)(y >> 32); }
+
+// ---- libstdc++ heap primitives on an LDS array (one thread): __adjust_heap (with its __push_heap tail), __make_heap
+__device__ void cv_adjust_heap(unsigned long long* hp, int hole, int len, unsigned long long value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (cv_gt(hp[child], hp[child - 1])) child--;
+    hp[hole] = hp[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    hp[hole] = hp[child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && cv_gt(hp[parent], value)) {
+    hp[hole] = hp[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  hp[hole] = value;
+}
+
+// std::__heap_select(a + first, a + middle, a + last, greater-by-key), introselect's fall-back when its depth limit is
+// reached: the heap [first, middle) lives in LDS while the tail is scanned; the scan is the workgroup's (256 elements per
+// step, the next element that beats the heap's top found by ballot), the heap operations are one thread's.
+__device__ void cv_heap_select(unsigned long long* a, int first, int middle, int last, unsigned long long* hp, CvLds& S) {
+  const int tid = threadIdx.x, len = middle - first;
+  for (int i = tid; i < len; i += 256) hp[i] = a[first + i];
+  __syncthreads();
+  if (tid == 0 && len >= 2) {
+    int parent = (len - 2) / 2;
+    for (;;) {
+      const unsigned long long value = hp[parent];
+      cv_adjust_heap(hp, parent, len, value);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  __syncthreads();
+  for (int base = middle; base < last; base += 256) {
+    const int idx = base + tid;
+    const unsigned long long mine = idx < last ? a[idx] : 0ull;
+    int done = base;   // elements of this chunk below `done` have been handled
+    for (;;) {
+      const unsigned long long top = hp[0];
+      const bool hit = idx < last && idx >= done && cv_gt(mine, top);
+      const unsigned long long bal = __ballot(hit);
+      if ((tid & 63) == 0) S.bc[tid >> 6] = bal ? (int)(tid + __ffsll((long long)bal) - 1) : 1 << 20;
+      __syncthreads();
+      const int j = min(min(S.bc[0], S.bc[1]), min(S.bc[2], S.bc[3]));   // thread index of the first hit
+      __syncthreads();
+      if (j >= 256) break;
+      if (tid == j) {
+        // __pop_heap(first, middle, result = a + idx)
+        a[idx] = top;
+        cv_adjust_heap(hp, 0, len, mine);
+      }
+      done = base + j + 1;
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < len; i += 256) a[first + i] = hp[i];
+  __syncthreads();
+}
+
+// libstdc++ std::nth_element(a + first, a + nth, a + last, greater-by-key); false = the heap of the depth-limit fall-back
+// does not fit the LDS array (cannot happen for nth <= 2 * quota: the launcher sizes it so)
+__device__ bool cv_introselect(unsigned long long* a, int first, int nth, int last, uint32_t* lpos, uint32_t* rpos, CvLds& S,
+                               unsigned long long* hp, int hp_cap) {
+  if (first == last || nth == last) return true;
+  int depth = 2 * (31 - __clz(last - first));
+  while (last - first > 3) {
+    if (depth == 0) {
+      if (nth + 1 - first > hp_cap) return false;
+      cv_heap_select(a, first, nth + 1, last, hp, S);
+      if (threadIdx.x == 0) {
+        const unsigned long long t = a[first];
+        a[first] = a[nth];
+        a[nth] = t;
+      }
+      __syncthreads();
+      return true;
+    }
+    --depth;
+    if (threadIdx.x == 0) {
+      // __move_median_to_first(first, first + 1, mid, last - 1)
+      const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+      const unsigned long long va = a[ia], vb = a[ib], vc = a[ic];
+      int pick;
+      if (cv_gt(va, vb)) pick = cv_gt(vb, vc) ? ib : (cv_gt(va, vc) ? ic : ia);
+      else pick = cv_gt(va, vc) ? ia : (cv_gt(vb, vc) ? ic : ib);
+      const unsigned long long t = a[first];
+      a[first] = a[pick];
+      a[pick] = t;
+    }
+    __syncthreads();
+    const uint32_t p = (uint32_t)(a[first] >> 32);
+    const int cut = cv_partition<0>(a, first + 1, last, p, lpos, rpos, S);
+    if (cut <= nth) first = cut; else last = cut;
+  }
+  if (threadIdx.x == 0) {
+    // __insertion_sort(first, last)
+    for (int i = first + 1; i < last; i++) {
+      const unsigned long long val = a[i];
+      if (cv_gt(val, a[first])) {
+        for (int j = i; j > first; j--) a[j] = a[j - 1];
+        a[first] = val;
+      } else {
+        int j = i;
+        while (cv_gt(val, a[j - 1])) { a[j] = a[j - 1]; --j; }
+        a[j] = val;
+      }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// KeyPointsFilter::retainBest on a[0, n): returns the new size, -1 when the fall-back heap does not fit
+__device__ int cv_retain_best(unsigned long long* a, int n, int npoints, uint32_t* lpos, uint32_t* rpos, CvLds& S,
+                              unsigned long long* hp, int hp_cap) {
+  if (npoints < 0 || n <= npoints) return n;
+  if (npoints == 0) return 0;
+  if (!cv_introselect(a, 0, npoints, n, lpos, rpos, S, hp, hp_cap)) return -1;
+  const uint32_t amb = (uint32_t)(a[npoints - 1] >> 32);
+  return cv_partition<1>(a, npoints, n, amb, lpos, rpos, S);
+}
+
+__device__ __forceinline__ float f32_from_order_key(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
+  const SelectArgs& A = B.s;
+  __shared__ CvLds S;
+  __shared__ int sh_run;
+  extern __shared__ unsigned long long cv_heap[];   // 2 * quota(level 0) + 2 entries
+  int l, f;
+  xcd_order(l, f);
+  if (f >= A.nframes) return;
+  const int tid = threadIdx.x;
+  const EvhLevel L = A.lv[l];
+  const uint32_t* cand = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
+  const int n_raw = A.cand_count[f * EVH_NLEVELS + l];
+  bool overflow = n_raw > L.cand_cap;
+  const int n = min(n_raw, L.cand_cap);
+  const int q = L.quota;
+  unsigned long long* a = B.seq + (int64_t)f * A.cand_frame_entries + L.cand_off;
+  uint32_t* lpos = B.lpos + (int64_t)f * A.cand_frame_entries + L.cand_off;
+  uint32_t* rpos = B.rpos + (int64_t)f * A.cand_frame_entries + L.cand_off;
+  int k2 = 0;
+  bool unsupported = false;
+  if (n > 0 && q > 0) {
+    // ---- the corners of the level in row-major order (FAST emits them so): bit plane -> running popcount -> rank
+    const int wpr = (L.w + 31) >> 5, nw = wpr * L.h;
+    uint32_t* mask = B.mask + (int64_t)f * 2 * B.mask_frame_words + B.mask_off[l];
+    uint32_t* pre = mask + B.mask_frame_words;
+    for (int i = tid; i < nw; i += 256) mask[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const uint32_t c = cand[i];
+      atomicOr(&mask[(int)((c >> 12) & 0xFFFu) * wpr + (int)((c & 0xFFFu) >> 5)], 1u << (c & 31u));
+    }
+    __syncthreads();
+    if (tid == 0) sh_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nw; base += 256) {
+      const int i = base + tid;
+      // the bits were set by atomics (performed in L2): read them past the CU's L1 as well
+      const int v = i < nw ? __popc(__hip_atomic_load(&mask[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+      int e, d0, t, d1;
+      cv_scan2(S, v, 0, e, d0, t, d1);
+      const int run = sh_run;
+      if (i < nw) pre[i] = (uint32_t)(run + e);
+      __syncthreads();
+      if (tid == 0) sh_run = run + t;
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) {
+      const uint32_t c = cand[i];
+      const int wi = (int)((c >> 12) & 0xFFFu) * wpr + (int)((c & 0xFFFu) >> 5);
+      const int rank = (int)pre[wi] + __popc(__hip_atomic_load(&mask[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1u << (c & 31u)) - 1u));
+      a[rank] = ((unsigned long long)(c >> 24) << 32) | c;
+    }
+    __syncthreads();
+    // ---- retainBest(2 * quota) by FAST score
+    int k1 = cv_retain_best(a, n, 2 * q, lpos, rpos, S, cv_heap, B.heap_cap);
+    if (k1 < 0) { unsupported = true; k1 = 0; }
+    // ---- Harris response of the survivors, in place
+    const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
+    for (int j = tid; j < k1; j += 256) {
+      const uint32_t c = (uint32_t)a[j];
+      const float r = harris_response(img, L.stride, (int)(c & 0xFFFu), (int)((c >> 12) & 0xFFFu));
+      a[j] = ((unsigned long long)f32_order_key(r) << 32) | c;
+    }
+    __syncthreads();
+    // ---- retainBest(quota) by Harris response
+    k2 = cv_retain_best(a, k1, q, lpos, rpos, S, cv_heap, B.heap_cap);
+    if (k2 < 0) { unsupported = true; k2 = 0; }
+    if (k2 > A.kcap) { overflow = true; k2 = A.kcap; }
+    for (int j = tid; j < k2; j += 256) {
+      const unsigned long long e = a[j];
+      const int64_t o = ((int64_t)f * EVH_NLEVELS + l) * A.kcap + j;
+      A.tmp_meta[o] = ((uint32_t)l << 24) | ((uint32_t)e & 0xFFFFFFu);
+      A.tmp_resp[o] = f32_from_order_key((uint32_t)(e >> 32));
+    }
+  }
+  if (tid == 0) {
+    A.lvl_count[f * EVH_NLEVELS + l] = k2;
+    if (overflow) atomicOr(&A.frame_flags[f], 1);
+    if (unsupported) atomicOr(&A.frame_flags[f], 2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K5 + K6: one wavefront per keypoint.  The 45x45 raw neighbourhood is staged in LDS once (16-byte loads) and serves the
 // intensity-centroid orientation (radius-15 disc), the 7x7 sigma-2 fixed-point Gaussian (only the 39x39 region
 // the steered taps can reach) and the 256 rotated BRIEF tests (4 x 64-lane ballots = the 32 descriptor bytes).
@@ -1693,7 +2034,8 @@ int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
     if (A.samp_mod[l]) nsamp += (tiles + A.samp_mod[l] - 1) / A.samp_mod[l];
   }
   const dim3 grid(c->g.total_tiles, nframes);
-  if (!c->fast_lift || nsamp == 0) {
+  // the reference's key-point order is a function of EVERY corner at threshold 20 (k_select_cv): no lifting there
+  if (!c->fast_lift || nsamp == 0 || c->order_mode == EVH_ORDER_OPENCV) {
     hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, c->stream, A);
     EVH_HIP(c, hipGetLastError());
     return EVH_SUCCESS;
@@ -1728,6 +2070,21 @@ int evh_launch_select(evh_ctx* c, int nframes) {
   A.k2cap = c->kcap;
   const size_t lds = sizeof(uint32_t) * 2 * ((size_t)A.k1cap + A.k2cap);
   A.nframes = nframes;
+  if (c->order_mode == EVH_ORDER_OPENCV) {
+    SelCvArgs B;
+    B.s = A;
+    B.seq = c->d_cv_seq; B.lpos = c->d_cv_lpos; B.rpos = c->d_cv_rpos; B.mask = c->d_cv_mask;
+    B.mask_frame_words = c->cv_mask_frame_words;
+    int mo = 0;
+    for (int l = 0; l < EVH_NLEVELS; l++) { B.mask_off[l] = mo; mo += ((A.lv[l].w + 31) / 32) * A.lv[l].h; }
+    if (mo > c->cv_mask_frame_words) return evh_fail(c, EVH_ERR_CAPACITY, "evh_launch_select: corner bit plane larger than the context's");
+    B.heap_cap = 2 * q0 + 2;
+    hipLaunchKernelGGL(k_select_cv, xcd_grid(EVH_NLEVELS, nframes), dim3(256), sizeof(unsigned long long) * (size_t)B.heap_cap, c->stream, B);
+    EVH_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, c->stream, A);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
   if (lds > 48 * 1024)   // from ~3000 key points on (74.7 KB at 4000): opt in to more dynamic LDS than the default
     EVH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));

@@ -98,6 +98,13 @@ struct evh_ctx {
   int* d_area_tab = nullptr;      // INTER_AREA tables of the last ingest geometry (evh_launch_ingest_level0)
   int64_t area_key = -1; int area_nx = 0, area_ny = 0;
   int* d_fast_redo = nullptr;     // [1 + max_frames*8] redo work list (count first)
+  // key-point order of the reference (EVH_ORDER_OPENCV): work arrays of k_select_cv
+  int order_mode = 1;             // EVH_ORDER_OPENCV
+  unsigned long long* d_cv_seq = nullptr;   // [max_frames][cand_frame_entries] key << 32 | candidate, row-major then permuted
+  uint32_t* d_cv_lpos = nullptr;  // [max_frames][cand_frame_entries] stopper positions of the partition passes
+  uint32_t* d_cv_rpos = nullptr;
+  uint32_t* d_cv_mask = nullptr;  // [max_frames][2][cv_mask_frame_words] corner bit plane + running popcount
+  int64_t cv_mask_frame_words = 0;
   bool fast_lift = true;
   bool fast_share = true;         // evh_set_fast_share
   bool fast_hint = true;          // evh_set_fast_hint

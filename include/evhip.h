@@ -126,6 +126,19 @@ int evh_orb_detect_batch(evh_ctx* ctx, const uint8_t* d_frames, int nframes, int
  * either way (a level that comes up short is redone at threshold 20).  With lifting off the candidate lists
  * returned by evh_orb_download_candidates hold every FAST corner at threshold 20.                          */
 int evh_set_fast_lift(evh_ctx* ctx, int on);
+/* Order (and, with ties at the cut, the set) in which ORB's KeyPointsFilter::retainBest leaves a level's key points --
+ * frame_processing.py:59-61 cv2.ORB_create().detectAndCompute; OpenCV 3.4.2 features2d/src/keypoint.cpp:
+ *     std::nth_element(begin, begin + n, end, greater-response); amb = kp[n - 1].response;
+ *     std::partition(begin + n, end, response >= amb)
+ * EVH_ORDER_OPENCV (default): the permutation libstdc++'s introselect / partition leave on the row-major list of a level's
+ *   FAST corners -- what the reference's run produces; the order of the matches, and through it the minimal samples RANSAC
+ *   draws, follow from it (pinned by the reference's dict_with_homography_matrix.json, tests/test_capture_golden.py).
+ *   Needs every corner at threshold 20, so FAST threshold lifting does not apply.
+ * EVH_ORDER_CANONICAL: every tie at the cut kept, key points in (level, y, x) order (rounds 1-3); faster (lifting applies),
+ *   H agrees with the reference only where RANSAC's consensus does not depend on the draw. */
+enum { EVH_ORDER_CANONICAL = 0, EVH_ORDER_OPENCV = 1 };
+int evh_set_keypoint_order(evh_ctx* ctx, int mode);
+int evh_get_keypoint_order(const evh_ctx* ctx);
 /* The pair / stream entries below additionally let the second frame of a pair -- every other frame of a stream --
  * borrow the sampled score histogram of the frame before it (default on): consecutive video frames look alike, and
  * a threshold that proves too high is redone at 20 like any other, so results never change.  Turn it off for

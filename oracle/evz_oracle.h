@@ -52,6 +52,7 @@ void evo_fast_score_map(const uint8_t* img, int w, int h, int threshold, uint8_t
  * other combinations of OpenCV's nth index and libstdc++'s pivot rule (evz_orb.cpp) */
 void evo_set_orb_order(int mode);
 int evo_get_orb_order(void);
+long evo_orb_depth_limit_hits(void);   /* nth_element calls so far that fell back to heap select (introselect depth limit) */
 int evo_orb_level_candidates(const uint8_t* img, int w, int h, int quota, int* xs, int* ys, int* scores, int cap);
 /* 7x7/sigma=2 8-bit Gaussian blur with reflect-101 borders (K6 first half) */
 void evo_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst);

@@ -330,6 +330,7 @@ void fast_nms(const uint8_t* img, int w, int h, int thr, std::vector<Corner>& ou
  * dict_with_homography_matrix.json within 1e-3 against 15 in mode 0, 78 in mode 2, 18 and 23 in modes 3 and 4) and is the default;
  * evo_set_orb_order() / the environment variable EVO_ORB_ORDER select another. */
 int g_order_mode = -1;
+long g_depth_hits = 0;   // nth_element calls that reached introselect's depth limit (heap-select fall-back)
 int order_mode() {
   if (g_order_mode < 0) { const char* e = getenv("EVO_ORB_ORDER"); g_order_mode = e ? atoi(e) : 1; }
   return g_order_mode;
@@ -403,6 +404,7 @@ void retain_best(std::vector<T>& v, int n, F resp) {
   const int nth = (mode == 1 || mode == 3) ? n : n - 1;
   std::vector<T> backup = v;
   if (!introselect(v.begin(), v.begin() + nth, v.end(), greater, mode >= 3)) {
+    ++g_depth_hits;
     if (mode >= 3) fprintf(stderr, "evz_orb: introselect depth limit reached (old-rule heap fall-back not emulated)\n");
     v = backup;
     std::nth_element(v.begin(), v.begin() + nth, v.end(), greater);
@@ -529,6 +531,7 @@ extern "C" void evo_sincos(double x, double* so, double* co) {
 
 extern "C" void evo_set_orb_order(int mode) { g_order_mode = (mode >= 0 && mode <= 4) ? mode : 1; }
 extern "C" int evo_get_orb_order(void) { return order_mode(); }
+extern "C" long evo_orb_depth_limit_hits(void) { return g_depth_hits; }
 
 extern "C" int evo_fast_nms(const uint8_t* img, int w, int h, int thr, int* xs, int* ys, int* scores, int cap) {
   std::vector<Corner> c;
