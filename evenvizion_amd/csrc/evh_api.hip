@@ -463,6 +463,7 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   A_(dalloc(c, &c->d_cv_lpos, F * (size_t)gmax.cand_frame_entries));
   A_(dalloc(c, &c->d_cv_rpos, F * (size_t)gmax.cand_frame_entries));
   A_(dalloc(c, &c->d_cv_mask, F * 2 * (size_t)c->cv_mask_frame_words));
+  A_(dalloc(c, &c->d_cv_tdesc, F * 8 * (size_t)gmax.total_tiles + 64));
   A_(dalloc(c, &c->d_fast_hint, 16 + 8 * 256 + 8));
   if (hipMemset(c->d_fast_hint, 0, sizeof(int) * (16 + 8 * 256 + 8)) != hipSuccess) {
     c->err = "hipMemset(d_fast_hint) failed";
@@ -494,7 +495,7 @@ void evh_destroy(evh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
-                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_cv_seq, c->d_cv_lpos, c->d_cv_rpos, c->d_cv_mask, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_cv_seq, c->d_cv_lpos, c->d_cv_rpos, c->d_cv_mask, c->d_cv_tdesc, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch, c->d_scan_ws, c->d_filter_ws, c->d_merge_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   evh_sift_free(c);

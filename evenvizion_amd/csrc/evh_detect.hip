@@ -527,6 +527,9 @@ struct FastArgs {
   int* thr;            // [F][8]
   unsigned* shist;     // [F][8][256]
   int* redo;           // [1 + F*8]: count, then the (frame * 8 + level) entries to redo densely
+  uint32_t* tdesc;     // reference order: [F][total_tiles][8] per-tile burst descriptor (offset in the level's list, 28 row counts)
+  int total_tiles;
+  int lift_base;       // 1: k_fast_main scores through the pre-test + queue machinery at the base threshold too (reference order)
   int samp_start[EVH_NLEVELS], samp_mod[EVH_NLEVELS];   // sampling lattice of k_fast_sample
   // consecutive frames of one video look alike: with share_group = F > 0 the frames of a call form groups of F
   // consecutive frames and a frame at an odd position of its group takes the sampled score histogram of the frame
@@ -627,12 +630,15 @@ struct FastLds {
   uint16_t scored[FSC_CAP];
   alignas(16) uint32_t sink[4];      // target of the second staging store of threads that have no second item
   int lcnt, gbase, qcnt, scnt, q1cnt;
+  int wtot[4];                       // ordered collection: survivors per wave of the current pass
+  uint32_t rowcnt[8];                // ordered collection: survivors per tile row, one byte each (FT_H = 28 rows)
 };
 
 // stage rows y0-4 .. y0+FT_H+3, columns x0-8 .. x0+135 with 16-byte loads (data outside the image reads as 0: it
 // only feeds pixels whose centre is outside the testable range, which are never scored); clears the counters
 __device__ __forceinline__ void fast_stage(FastLds& S, const uint8_t* img, const EvhLevel& L, int x0, int y0) {
   if (threadIdx.x == 0) { S.lcnt = 0; S.qcnt = 0; S.scnt = 0; S.q1cnt = 0; }
+  if (threadIdx.x >= 8 && threadIdx.x < 16) S.rowcnt[threadIdx.x - 8] = 0;
   // 16-byte items (x0 - 8 = 16 + 128 tx is 16-byte aligned, a staged row is 9 of them): item i = (row i / 9,
   // column i % 9), 324 items = 2 per thread at most; +256 items = +28 rows +4 columns.  Rows are padded to 64 bytes,
   // so an item is wholly inside [0, stride) or wholly outside.
@@ -956,6 +962,96 @@ __device__ __forceinline__ void fast_nms_collect(FastLds& S, const EvhLevel& L, 
   }
 }
 
+// The same suppression with the survivors left in ROW-MAJOR order (reference key-point order: FAST hands its corners over
+// row by row, and k_select_cv rebuilds a level's row-major list from the tiles' ordered bursts).  Wave w owns tile rows
+// 7w .. 7w+6 and walks them two rows (64 quads) a step, so its survivors come out in order from ballots alone -- no
+// barrier; they go to the wave's quarter of S.lst (at most one survivor per 2x2 block: <= 256 per wave).  S.wtot receives
+// the survivors per wave, S.rowcnt the survivors per tile row (a byte each).
+__device__ __forceinline__ void fast_nms_collect_ordered(FastLds& S, const EvhLevel& L, int x0, int y0) {
+  const bool live = (L.w > 2 * EVH_EDGE) && (L.h > 2 * EVH_EDGE);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  static_assert(FT_H == 28 && FT_W == 128, "four waves x seven rows of 32 quads");
+  uint32_t* mine = S.lst + 256 * wv;
+  int running = 0;
+  uint32_t rc_lo = 0, rc_hi = 0;        // survivors of this wave's rows 0..3 / 4..6, a byte each (lane 0 keeps them)
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) {
+    const int local = 64 * k + lane;    // quad index inside the wave's 7 x 32 block
+    uint32_t v0 = 0, v1 = 0;
+    int cnt = 0;
+    if (live && local < 7 * 32) {
+      const int qr = 7 * wv + (local >> 5), qc = local & 31;
+      const int y = y0 + qr, xq = x0 + qc * 4;
+      const uint32_t* p = S.score + (qr + 1) * FS_DW + (qc + 1);
+      const uint32_t m = p[0];
+      if (m != 0 && y >= EVH_EDGE && y < L.h - EVH_EDGE) {
+        const uint32_t lft = p[-1], rgt = p[1];
+        const uint32_t um = p[-FS_DW], ul = p[-FS_DW - 1], ur = p[-FS_DW + 1];
+        const uint32_t dm = p[FS_DW], dl = p[FS_DW - 1], dr = p[FS_DW + 1];
+        const uint64_t wu = ((uint64_t)ur << 40) | ((uint64_t)um << 8) | (ul >> 24);
+        const uint64_t wm = ((uint64_t)rgt << 40) | ((uint64_t)m << 8) | (lft >> 24);
+        const uint64_t wd = ((uint64_t)dr << 40) | ((uint64_t)dm << 8) | (dl >> 24);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int sc = (int)((wm >> (8 * (j + 1))) & 0xFF);
+          const int x = xq + j;
+          if (sc == 0 || x < EVH_EDGE || x >= L.w - EVH_EDGE) continue;
+          const int n0 = (int)((wm >> (8 * j)) & 0xFF), n1 = (int)((wm >> (8 * (j + 2))) & 0xFF);
+          const int u0 = (int)((wu >> (8 * j)) & 0xFF), u1 = (int)((wu >> (8 * (j + 1))) & 0xFF), u2 = (int)((wu >> (8 * (j + 2))) & 0xFF);
+          const int d0 = (int)((wd >> (8 * j)) & 0xFF), d1 = (int)((wd >> (8 * (j + 1))) & 0xFF), d2 = (int)((wd >> (8 * (j + 2))) & 0xFF);
+          if (sc > n0 && sc > n1 && sc > u0 && sc > u1 && sc > u2 && sc > d0 && sc > d1 && sc > d2) {
+            const uint32_t e = ((uint32_t)sc << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+            if (cnt == 0) v0 = e; else v1 = e;
+            cnt++;
+          }
+        }
+      }
+    }
+    const unsigned long long m1 = __ballot(cnt >= 1), m2 = __ballot(cnt >= 2);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int pre = running + __popcll(m1 & lt) + __popcll(m2 & lt);
+    if (cnt >= 1) mine[pre] = v0;
+    if (cnt >= 2) mine[pre + 1] = v1;
+    running += __popcll(m1) + __popcll(m2);
+    const uint32_t ra = (uint32_t)(__popcll(m1 & 0xFFFFFFFFull) + __popcll(m2 & 0xFFFFFFFFull));
+    const uint32_t rb = (uint32_t)(__popcll(m1 >> 32) + __popcll(m2 >> 32));
+    if (k < 2) rc_lo |= (ra << (16 * k)) | (rb << (16 * k + 8));
+    else rc_hi |= (ra << (16 * (k - 2))) | (rb << (16 * (k - 2) + 8));
+  }
+  if (lane == 0) {
+    S.wtot[wv] = running;
+    // tile row 7w + i -> byte (7w + i) & 3 of word (7w + i) >> 2; the rows of different waves share words: LDS atomics
+    for (int i = 0; i < 7; i++) {
+      const uint32_t c = i < 4 ? (rc_lo >> (8 * i)) & 0xFFu : (rc_hi >> (8 * (i - 4))) & 0xFFu;
+      const int row = 7 * wv + i;
+      if (c) atomicOr(&S.rowcnt[row >> 2], c << (8 * (row & 3)));
+    }
+  }
+}
+
+// ordered bursts: the four waves' quarters of S.lst one after another, then the tile's descriptor for k_select_cv
+// (word 0 = offset of the burst in the level's candidate list, words 1..7 = survivors per tile row)
+__device__ __forceinline__ void fast_emit_ordered(FastLds& S, const FastArgs& A, const EvhLevel& L, int f, int l, int tile) {
+  __syncthreads();
+  const int n0 = S.wtot[0], n1 = S.wtot[1], n2 = S.wtot[2], n = n0 + n1 + n2 + S.wtot[3];
+  if (n > 0) {                                              // workgroup-uniform
+    if (threadIdx.x == 0) S.gbase = atomicAdd(A.cand_count + f * EVH_NLEVELS + l, n);
+    __syncthreads();
+  }
+  const int base = n > 0 ? S.gbase : 0;
+  if (n > 0) {
+    uint32_t* out = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cnt = S.wtot[wv], off = wv == 0 ? 0 : wv == 1 ? n0 : wv == 2 ? n0 + n1 : n0 + n1 + n2;
+    for (int i = lane; i < cnt; i += 64)
+      if (base + off + i < L.cand_cap) out[base + off + i] = S.lst[256 * wv + i];
+  }
+  if (threadIdx.x < 8) {
+    uint32_t* d = A.tdesc + ((int64_t)f * A.total_tiles + tile) * 8;
+    d[threadIdx.x] = threadIdx.x == 0 ? (uint32_t)base : S.rowcnt[threadIdx.x - 1];
+  }
+}
+
 // survivors -> the level's candidate list; ONE global atomic per workgroup reserves the slots (a returning global
 // atomic per wave would serialise on its ~1-2 us latency)
 __device__ __forceinline__ void fast_emit(FastLds& S, const FastArgs& A, const EvhLevel& L, int f, int l) {
@@ -1009,6 +1105,11 @@ __global__ __launch_bounds__(256) void k_fast(FastArgs A) {
   __syncthreads();
   fast_dense_scores(S, L, x0, y0);
   __syncthreads();
+  if (A.tdesc) {                                   // reference key-point order (workgroup-uniform)
+    fast_nms_collect_ordered(S, L, x0, y0);
+    fast_emit_ordered(S, A, L, f, l, (int)blockIdx.x);
+    return;
+  }
   fast_nms_collect(S, L, x0, y0);
   fast_emit(S, A, L, f, l);
 }
@@ -1099,10 +1200,10 @@ __global__ __launch_bounds__(256, 8) void k_fast_main(FastArgs A) {
   const EvhLevel L = A.lv[l];
   const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
   const int x0 = EVH_FAST_OX + tx * FT_W, y0 = EVH_FAST_OY + ty * FT_H;
-  const int T = A.thr[f * EVH_NLEVELS + l];
+  const int T = A.lift_base ? EVH_FAST_THR : A.thr[f * EVH_NLEVELS + l];
   fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
   __syncthreads();
-  if (T > EVH_FAST_THR) {
+  if (T > EVH_FAST_THR || A.lift_base) {
     fast_lift_scores(S, L, x0, y0, T);
     __syncthreads();
     if (S.scnt <= FSC_CAP) {                      // workgroup-uniform.  What is left is a few dozen scored pixels:
@@ -1428,7 +1529,10 @@ struct SelCvArgs {
   uint32_t* mask;            // [nframes][2 * mask_frame_words] corner bit plane, then its running popcount
   int64_t mask_frame_words;
   int mask_off[EVH_NLEVELS];
+  const uint32_t* tdesc;     // [nframes][total_tiles][8] tile burst descriptors written by k_fast
+  int total_tiles;
   int heap_cap;              // entries of the dynamic LDS heap (>= 2 * largest quota + 1)
+  int phase_limit;           // profiling aid: 1 = stop after the row-major sequence, 2 = after the first retainBest, 0 = all
 };
 
 struct CvLds {
@@ -1461,9 +1565,11 @@ __device__ __forceinline__ void cv_scan2(CvLds& S, int a, int b, int& ea, int& e
 
 // Partition pass over a[lo, hi).  MODE 0: Hoare around the pivot key p (left stoppers key <= p, right stoppers key >= p),
 // returns the cut.  MODE 1: std::partition with the predicate key >= p (left stoppers !pred, right stoppers pred), returns
-// the position of the first element of the false group.
-template <int MODE>
-__device__ int cv_partition(unsigned long long* a, int lo, int hi, uint32_t p, uint32_t* lpos, uint32_t* rpos, CvLds& S) {
+// the position of the first element of the false group.  EP / LP: element and position-list pointers (global memory with
+// 32-bit positions, or the LDS copy of a short range with 16-bit positions).
+template <int MODE, class EP, class LP>
+__device__ int cv_partition(EP a, int lo, int hi, uint32_t p, LP lpos, LP rpos, CvLds& S) {
+  typedef typename std::remove_pointer<LP>::type PT;
   const int tid = threadIdx.x;
   int cntL = 0, cntR = 0;
   for (int base = lo; base < hi; base += 1024) {
@@ -1483,8 +1589,8 @@ __device__ int cv_partition(unsigned long long* a, int lo, int hi, uint32_t p, u
     cv_scan2(S, __popc(fl), __popc(fr), el, er, tl, tr);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      if ((fl >> e) & 1u) lpos[cntL + el++] = (uint32_t)(i0 + e);
-      if ((fr >> e) & 1u) rpos[cntR + er++] = (uint32_t)(i0 + e);
+      if ((fl >> e) & 1u) lpos[cntL + el++] = (PT)(i0 + e);
+      if ((fr >> e) & 1u) rpos[cntR + er++] = (PT)(i0 + e);
     }
     cntL += tl;
     cntR += tr;
@@ -1497,7 +1603,7 @@ __device__ int cv_partition(unsigned long long* a, int lo, int hi, uint32_t p, u
     const int span = hi_k - lo_k;
     const int step = (span + 255) / 256;
     const int k = lo_k + tid * step;
-    const bool ok = k < hi_k && lpos[k] < rpos[cntR - 1 - k];
+    const bool ok = k < hi_k && (int)lpos[k] < (int)rpos[cntR - 1 - k];
     const unsigned long long bal = __ballot(ok);
     if ((tid & 63) == 0) S.bc[tid >> 6] = __popcll(bal);
     __syncthreads();
@@ -1510,7 +1616,7 @@ __device__ int cv_partition(unsigned long long* a, int lo, int hi, uint32_t p, u
   }
   const int m = lo_k;
   for (int k = tid; k < m; k += 256) {
-    const uint32_t i = lpos[k], j = rpos[cntR - 1 - k];
+    const int i = (int)lpos[k], j = (int)rpos[cntR - 1 - k];
     const unsigned long long t = a[i];
     a[i] = a[j];
     a[j] = t;
@@ -1556,7 +1662,8 @@ __device__ void cv_adjust_heap(unsigned long long* hp, int hole, int len, unsign
 // std::__heap_select(a + first, a + middle, a + last, greater-by-key), introselect's fall-back when its depth limit is
 // reached: the heap [first, middle) lives in LDS while the tail is scanned; the scan is the workgroup's (256 elements per
 // step, the next element that beats the heap's top found by ballot), the heap operations are one thread's.
-__device__ void cv_heap_select(unsigned long long* a, int first, int middle, int last, unsigned long long* hp, CvLds& S) {
+template <class EP>
+__device__ void cv_heap_select(EP a, int first, int middle, int last, unsigned long long* hp, CvLds& S) {
   const int tid = threadIdx.x, len = middle - first;
   for (int i = tid; i < len; i += 256) hp[i] = a[first + i];
   __syncthreads();
@@ -1596,13 +1703,31 @@ __device__ void cv_heap_select(unsigned long long* a, int first, int middle, int
   __syncthreads();
 }
 
-// libstdc++ std::nth_element(a + first, a + nth, a + last, greater-by-key); false = the heap of the depth-limit fall-back
-// does not fit the LDS array (cannot happen for nth <= 2 * quota: the launcher sizes it so)
-__device__ bool cv_introselect(unsigned long long* a, int first, int nth, int last, uint32_t* lpos, uint32_t* rpos, CvLds& S,
-                               unsigned long long* hp, int hp_cap) {
-  if (first == last || nth == last) return true;
-  int depth = 2 * (31 - __clz(last - first));
+// a range of at most CV_SMALL elements is worked on in LDS: a round then costs LDS latencies instead of a chain of
+// dependent global accesses (pivot, cut, lists), which is what the small pyramid levels and the last rounds of the large
+// ones consist of
+#define CV_SMALL 2048
+struct CvSmall {
+  unsigned long long a[CV_SMALL];
+  uint16_t l[CV_SMALL], r[CV_SMALL];
+};
+
+// libstdc++ __introselect on a[first, last) with `depth` rounds left; false = the heap of the depth-limit fall-back does
+// not fit the LDS array (cannot happen for nth <= 2 * quota: the launcher sizes it so)
+template <class EP, class LP>
+__device__ bool cv_introselect_loop(EP a, int first, int nth, int last, int depth, LP lpos, LP rpos, CvLds& S,
+                                    unsigned long long* hp, int hp_cap, CvSmall* sm) {
   while (last - first > 3) {
+    if constexpr (std::is_same<LP, uint32_t*>::value) if (sm && last - first <= CV_SMALL) {   // (the LDS instantiation never stages)
+      const int len = last - first;
+      for (int i = threadIdx.x; i < len; i += 256) sm->a[i] = a[first + i];
+      __syncthreads();
+      const bool ok = cv_introselect_loop<unsigned long long*, uint16_t*>(sm->a, 0, nth - first, len, depth, sm->l, sm->r, S, hp,
+                                                                           hp_cap, nullptr);
+      for (int i = threadIdx.x; i < len; i += 256) a[first + i] = sm->a[i];
+      __syncthreads();
+      return ok;
+    }
     if (depth == 0) {
       if (nth + 1 - first > hp_cap) return false;
       cv_heap_select(a, first, nth + 1, last, hp, S);
@@ -1649,12 +1774,25 @@ __device__ bool cv_introselect(unsigned long long* a, int first, int nth, int la
   return true;
 }
 
-// KeyPointsFilter::retainBest on a[0, n): returns the new size, -1 when the fall-back heap does not fit
+// KeyPointsFilter::retainBest on a[0, n): std::nth_element(a, a + npoints, a + n), then std::partition of the tail by
+// "response >= a[npoints - 1].response".  Returns the new size, -1 when the fall-back heap does not fit.
 __device__ int cv_retain_best(unsigned long long* a, int n, int npoints, uint32_t* lpos, uint32_t* rpos, CvLds& S,
-                              unsigned long long* hp, int hp_cap) {
+                              unsigned long long* hp, int hp_cap, CvSmall* sm) {
   if (npoints < 0 || n <= npoints) return n;
   if (npoints == 0) return 0;
-  if (!cv_introselect(a, 0, npoints, n, lpos, rpos, S, hp, hp_cap)) return -1;
+  const int depth = 2 * (31 - __clz(n));
+  if (n <= CV_SMALL) {                       // everything in LDS, the survivors copied back
+    for (int i = threadIdx.x; i < n; i += 256) sm->a[i] = a[i];
+    __syncthreads();
+    if (!cv_introselect_loop<unsigned long long*, uint16_t*>(sm->a, 0, npoints, n, depth, sm->l, sm->r, S, hp, hp_cap, nullptr))
+      return -1;
+    const uint32_t amb = (uint32_t)(sm->a[npoints - 1] >> 32);
+    const int k = cv_partition<1>(sm->a, npoints, n, amb, sm->l, sm->r, S);
+    for (int i = threadIdx.x; i < k; i += 256) a[i] = sm->a[i];
+    __syncthreads();
+    return k;
+  }
+  if (!cv_introselect_loop<unsigned long long*, uint32_t*>(a, 0, npoints, n, depth, lpos, rpos, S, hp, hp_cap, sm)) return -1;
   const uint32_t amb = (uint32_t)(a[npoints - 1] >> 32);
   return cv_partition<1>(a, npoints, n, amb, lpos, rpos, S);
 }
@@ -1666,7 +1804,7 @@ __device__ __forceinline__ float f32_from_order_key(uint32_t k) {
 __global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
   const SelectArgs& A = B.s;
   __shared__ CvLds S;
-  __shared__ int sh_run;
+  __shared__ CvSmall SM;
   extern __shared__ unsigned long long cv_heap[];   // 2 * quota(level 0) + 2 entries
   int l, f;
   xcd_order(l, f);
@@ -1684,41 +1822,64 @@ __global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
   int k2 = 0;
   bool unsupported = false;
   if (n > 0 && q > 0) {
-    // ---- the corners of the level in row-major order (FAST emits them so): bit plane -> running popcount -> rank
-    const int wpr = (L.w + 31) >> 5, nw = wpr * L.h;
-    uint32_t* mask = B.mask + (int64_t)f * 2 * B.mask_frame_words + B.mask_off[l];
-    uint32_t* pre = mask + B.mask_frame_words;
-    for (int i = tid; i < nw; i += 256) mask[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-      const uint32_t c = cand[i];
-      atomicOr(&mask[(int)((c >> 12) & 0xFFFu) * wpr + (int)((c & 0xFFFu) >> 5)], 1u << (c & 31u));
+    // ---- the corners of the level in row-major order (as cv::FAST hands them over).  Every FAST tile left its corners as one
+    // row-major burst in the level's list, with a descriptor (offset, corners per tile row): the place of a corner is
+    // (corners in earlier rows of the level) + (corners of its row in tiles to the left) + (its rank in its tile's row).
+    const int TX = L.tiles_x, TY = L.tiles_y, NE = TY * FT_H * TX;
+    uint32_t* P = B.mask + (int64_t)f * 2 * B.mask_frame_words + B.mask_off[l];   // exclusive prefix in (tile row, row, tile column) order
+    const uint32_t* td = B.tdesc + ((int64_t)f * B.total_tiles + L.tile_start) * 8;
+    {
+      const int per = (NE + 255) / 256, e0 = tid * per, e1 = min(NE, e0 + per);
+      int sum = 0;
+      for (int e = e0; e < e1; e++) {
+        const int tx = e % TX, rr = e / TX, r = rr % FT_H, ty = rr / FT_H;
+        sum += (int)((td[(ty * TX + tx) * 8 + 1 + (r >> 2)] >> (8 * (r & 3))) & 0xFFu);
+      }
+      int ex, d0, tot, d1;
+      cv_scan2(S, sum, 0, ex, d0, tot, d1);
+      for (int e = e0; e < e1; e++) {
+        const int tx = e % TX, rr = e / TX, r = rr % FT_H, ty = rr / FT_H;
+        P[e] = (uint32_t)ex;
+        ex += (int)((td[(ty * TX + tx) * 8 + 1 + (r >> 2)] >> (8 * (r & 3))) & 0xFFu);
+      }
+      if (tot != n) overflow = true;    // cannot happen: the descriptors and the list come from the same tiles
     }
     __syncthreads();
-    if (tid == 0) sh_run = 0;
-    __syncthreads();
-    for (int base = 0; base < nw; base += 256) {
-      const int i = base + tid;
-      // the bits were set by atomics (performed in L2): read them past the CU's L1 as well
-      const int v = i < nw ? __popc(__hip_atomic_load(&mask[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
-      int e, d0, t, d1;
-      cv_scan2(S, v, 0, e, d0, t, d1);
-      const int run = sh_run;
-      if (i < nw) pre[i] = (uint32_t)(run + e);
-      __syncthreads();
-      if (tid == 0) sh_run = run + t;
-      __syncthreads();
+    {
+      const int lane = tid & 63, wv = tid >> 6;
+      for (int t = wv; t < TX * TY; t += 4) {
+        const int ty = t / TX, tx = t - ty * TX;
+        const uint32_t wd = lane < 8 ? td[t * 8 + lane] : 0u;
+        const int base = (int)__shfl(wd, 0);
+        // corners per tile row in lanes 0..27, their exclusive prefix = first burst index of the row
+        const uint32_t cw = __shfl(wd, 1 + (min(lane, FT_H - 1) >> 2));
+        const int c = lane < FT_H ? (int)((cw >> (8 * (lane & 3))) & 0xFFu) : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        const int start = inc - c;
+        const int total = __shfl(inc, FT_H - 1);
+        for (int j = lane; j < ((total + 63) & ~63); j += 64) {
+          uint32_t cnd = 0;
+          int r = 0;
+          if (j < total) {
+            cnd = cand[base + j];
+            r = (int)((cnd >> 12) & 0xFFFu) - (EVH_FAST_OY + ty * FT_H);
+          }
+          const int st = __shfl(start, r);
+          if (j < total) {
+            const int pos = (int)P[(ty * FT_H + r) * TX + tx] + (j - st);
+            a[pos] = ((unsigned long long)(cnd >> 24) << 32) | cnd;
+          }
+        }
+      }
     }
-    for (int i = tid; i < n; i += 256) {
-      const uint32_t c = cand[i];
-      const int wi = (int)((c >> 12) & 0xFFFu) * wpr + (int)((c & 0xFFFu) >> 5);
-      const int rank = (int)pre[wi] + __popc(__hip_atomic_load(&mask[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1u << (c & 31u)) - 1u));
-      a[rank] = ((unsigned long long)(c >> 24) << 32) | c;
-    }
     __syncthreads();
+    if (B.phase_limit == 1) return;
     // ---- retainBest(2 * quota) by FAST score
-    int k1 = cv_retain_best(a, n, 2 * q, lpos, rpos, S, cv_heap, B.heap_cap);
+    int k1 = cv_retain_best(a, n, 2 * q, lpos, rpos, S, cv_heap, B.heap_cap, &SM);
     if (k1 < 0) { unsupported = true; k1 = 0; }
+    if (B.phase_limit == 2) return;
     // ---- Harris response of the survivors, in place
     const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
     for (int j = tid; j < k1; j += 256) {
@@ -1728,7 +1889,7 @@ __global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
     }
     __syncthreads();
     // ---- retainBest(quota) by Harris response
-    k2 = cv_retain_best(a, k1, q, lpos, rpos, S, cv_heap, B.heap_cap);
+    k2 = cv_retain_best(a, k1, q, lpos, rpos, S, cv_heap, B.heap_cap, &SM);
     if (k2 < 0) { unsupported = true; k2 = 0; }
     if (k2 > A.kcap) { overflow = true; k2 = A.kcap; }
     for (int j = tid; j < k2; j += 256) {
@@ -2034,7 +2195,13 @@ int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
     if (A.samp_mod[l]) nsamp += (tiles + A.samp_mod[l] - 1) / A.samp_mod[l];
   }
   const dim3 grid(c->g.total_tiles, nframes);
-  // the reference's key-point order is a function of EVERY corner at threshold 20 (k_select_cv): no lifting there
+  A.lift_base = 0;
+  A.tdesc = c->order_mode == EVH_ORDER_OPENCV ? c->d_cv_tdesc : nullptr;
+  A.total_tiles = c->g.total_tiles;
+  // the reference's key-point order is a function of EVERY corner at threshold 20 (k_select_cv): the threshold cannot be
+  // lifted there, but the exact score is still only needed where the 4-point pre-test at 20 passes
+  // (measured and dropped: the lifted machinery at the base threshold, k_fast_main with lift_base = 1 -- 22.8 ms against
+  // 19.8 ms for the dense kernel on the 720p texture of SURVEY 8d, where the 4-point pre-test at 20 passes most quads)
   if (!c->fast_lift || nsamp == 0 || c->order_mode == EVH_ORDER_OPENCV) {
     hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, c->stream, A);
     EVH_HIP(c, hipGetLastError());
@@ -2079,6 +2246,8 @@ int evh_launch_select(evh_ctx* c, int nframes) {
     for (int l = 0; l < EVH_NLEVELS; l++) { B.mask_off[l] = mo; mo += ((A.lv[l].w + 31) / 32) * A.lv[l].h; }
     if (mo > c->cv_mask_frame_words) return evh_fail(c, EVH_ERR_CAPACITY, "evh_launch_select: corner bit plane larger than the context's");
     B.heap_cap = 2 * q0 + 2;
+    B.tdesc = c->d_cv_tdesc; B.total_tiles = c->g.total_tiles;
+    { const char* e = getenv("EVH_CV_PHASE"); B.phase_limit = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(k_select_cv, xcd_grid(EVH_NLEVELS, nframes), dim3(256), sizeof(unsigned long long) * (size_t)B.heap_cap, c->stream, B);
     EVH_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, c->stream, A);

@@ -103,7 +103,8 @@ struct evh_ctx {
   unsigned long long* d_cv_seq = nullptr;   // [max_frames][cand_frame_entries] key << 32 | candidate, row-major then permuted
   uint32_t* d_cv_lpos = nullptr;  // [max_frames][cand_frame_entries] stopper positions of the partition passes
   uint32_t* d_cv_rpos = nullptr;
-  uint32_t* d_cv_mask = nullptr;  // [max_frames][2][cv_mask_frame_words] corner bit plane + running popcount
+  uint32_t* d_cv_mask = nullptr;  // [max_frames][2][cv_mask_frame_words] prefix table of the tiles' row counts
+  uint32_t* d_cv_tdesc = nullptr; // [max_frames][total_tiles][8] FAST tile burst descriptors
   int64_t cv_mask_frame_words = 0;
   bool fast_lift = true;
   bool fast_share = true;         // evh_set_fast_share
