@@ -10,8 +10,11 @@ writes, like the reference, under  <cwd>/<experiment_name>/<video stem>/ :
 and, as a data file instead of the reference's rendered comparison video (:69-97),
     fixed_coordinates.json             from_original_to_fix(original coordinates) per frame.
 
-Differences, all deliberate: there is no video decoder in this image (no cv2), so --path_to_video takes a .npy file
-(uint8 [F,h,w,3] BGR or [F,h,w] gray) or "synthetic:<frames>:<w>x<h>[:<seed>]"; the heat-map and matching PICTURES are
+--path_to_video takes what the reference's script takes for H.264 video in an MP4/MOV container: the file is opened by
+evenvizion_amd.capture.VideoCapture (libevcap.so: this repository's own demultiplexer + H.264 decoder, standing in for
+cv2.VideoCapture at evenvizion_component.py:132), e.g. the reference's own evenvizion/examples/test_video/test_video.mp4.
+It also takes a .npy file (uint8 [F,h,w,3] BGR or [F,h,w] gray) or "synthetic:<frames>:<w>x<h>[:<seed>]".
+Differences, all deliberate: the heat-map and matching PICTURES are
 not rendered (--show_matching_visualization must stay off); --resize_width is honoured (the reference script parses
 it but never passes it on, so it always runs at 400 -- the default here).
 """
@@ -26,6 +29,22 @@ def _bool(v):
     if isinstance(v, bool):
         return v
     return str(v).strip().lower() not in ("0", "false", "no", "none", "")
+
+
+VIDEO_SUFFIXES = (".mp4", ".mov", ".m4v")
+
+
+def open_capture(spec):
+    """-> (capture with .read() like cv2.VideoCapture, [h, w] of its frames, stem used for the output folder)"""
+    from .synthetic import SyntheticCapture
+    if spec.lower().endswith(VIDEO_SUFFIXES):
+        from . import capture
+        cap = capture.VideoCapture(spec)                                  # evenvizion_component.py:132
+        if not cap.isOpened():
+            raise ValueError("cannot open video %s: %s" % (spec, cap.open_error))
+        return cap, [cap.height, cap.width], os.path.split(spec)[-1].split(".")[0]
+    frames, stem = load_frames(spec)
+    return SyntheticCapture(frames), [int(frames[0].shape[0]), int(frames[0].shape[1])], stem
 
 
 def load_frames(spec):
@@ -59,19 +78,17 @@ def main(argv=None):
     if _bool(args.show_matching_visualization):
         raise NotImplementedError("matching pictures are outside the MI355X hot path; leave --show_matching_visualization off")
 
-    from .synthetic import SyntheticCapture
     from .processing.video_processing import get_homography_dict
     from .processing.utils import read_homography_dict, superposition_dict, read_json_with_coordinates, \
         are_infinity_coordinates
     from .processing.fixed_coordinate_system import from_original_to_fix
     from . import heatmap
 
-    frames, stem = load_frames(args.path_to_video)
-    original_shape = [int(frames[0].shape[0]), int(frames[0].shape[1])]
+    cap, original_shape, stem = open_capture(args.path_to_video)
     save_folder = os.path.join(os.getcwd(), args.experiment_name, stem)
     os.makedirs(save_folder, exist_ok=True)
 
-    result = get_homography_dict(SyntheticCapture(frames), resize_width=args.resize_width, matching_path=None,
+    result = get_homography_dict(cap, resize_width=args.resize_width, matching_path=None,
                                  none_H_processing=_bool(args.none_H_processing),
                                  features_type_list=[f for f in args.features.split(",") if f])
     path_to_homography_dict = os.path.join(save_folder, "dict_with_homography_matrix.json")
