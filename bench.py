@@ -80,6 +80,9 @@ def parse_args():
     ap.add_argument("--no-temporal", action="store_true", help="switch off the two exact shortcuts that lean on consecutive frames / calls looking alike (threshold sharing inside a pair, threshold hint across calls) for the MAIN timed loop")
     ap.add_argument("--force-max-iters", action="store_true", help="stream configs: evaluate all 2000 RANSAC samples (fixed-iteration stress variant)")
     ap.add_argument("--smooth", type=int, default=0, help="3x3 box-blur passes over the synthetic frames (content with fewer, weaker corners; informational)")
+    ap.add_argument("--order", choices=["reference", "canonical"], default="reference",
+                    help="ORB key-point order (include/evhip.h evh_set_keypoint_order): reference = OpenCV 3.4.2 on libstdc++, what the "
+                         "reference's recorded run agrees with (default); canonical = all ties, (level, y, x) order, FAST threshold lifting applies")
     ap.add_argument("--skip-no-temporal", action="store_true", help="do not time the extra no-temporal loop (profiling runs: every launch of the run is then the same workload)")
     ap.add_argument("--gen-procs", type=int, default=0, help="host processes that generate the synthetic pairs (0 = auto; use 1 under rocprofv3: no child processes)")
     ap.add_argument("--sync-solve", action="store_true",
@@ -319,6 +322,8 @@ def main():
         return el
 
     set_temporal(not args.no_temporal)
+    for c_ in ctxs:
+        c_.set_keypoint_order(1 if args.order == "reference" else 0)
     for _ in range(max(args.warmup, NCTX)):
         step()
     torch.cuda.synchronize(dev)
@@ -360,6 +365,19 @@ def main():
         nt_steps = max(2, min(args.steps, 10))
         no_temporal_value = round(pairs_per_step * nt_steps / timed(nt_steps), 2)
         set_temporal(True)
+
+    # the same loop in the canonical key-point order (rounds 1-3: all ties, (level, y, x) order; FAST threshold lifting applies):
+    # faster, but H then agrees with the reference's OpenCV run only where RANSAC's consensus does not depend on the draw
+    canonical_order_value = None
+    if args.order == "reference" and args.kind == "pairs" and not args.skip_no_temporal:
+        for c_ in ctxs:
+            c_.set_keypoint_order(0)
+        for _ in range(2):
+            step()
+        co_steps = max(2, min(args.steps, 10))
+        canonical_order_value = round(pairs_per_step * co_steps / timed(co_steps), 2)
+        for c_ in ctxs:
+            c_.set_keypoint_order(1)
 
     # ---- roofline of the dominant kernel group --------------------------------------------------------------------
     per_frame, per_pair = algorithmic_bytes(w, h, nfeat, args.channels)
@@ -507,6 +525,8 @@ def main():
                        "pairs_ok_fraction": ok_frac, "smooth_passes": args.smooth,
                        "fast_threshold_sharing_in_pair": not args.no_temporal, "fast_threshold_hint_across_calls": not args.no_temporal,
                        "no_temporal_value": no_temporal_value,
+                       "keypoint_order": "OpenCV 3.4.2 retainBest on libstdc++ nth_element/partition (the reference's; every FAST corner at threshold 20 is scored)" if args.order == "reference" else "canonical (all ties, level/y/x)",
+                       "canonical_order_value": canonical_order_value,
                        "arithmetic": "u8/i32 pixels+descriptors, f32 Harris+reprojection, f64 DLT+LM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -17,6 +17,7 @@ EVH_SUCCESS = 0
 PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_FEW_MATCHES, PAIR_NO_PROVISIONAL_H, PAIR_LOW_INLIER_RATIO, PAIR_NO_FINAL_H, \
     PAIR_CAPACITY = range(7)
 ORDER_CANONICAL, ORDER_OPENCV = 0, 1
+MAX_FEATURES = 5984   # EVH_MAX_FEATURES (include/evhip.h): largest max_features a context accepts
 MODE_INDEPENDENT_PAIRS, MODE_STREAM = 0, 1
 
 # every symbol include/evhip.h declares, with its ctypes signature

@@ -353,10 +353,13 @@ int pairs_types(evh_ctx* c, const char* who, const uint8_t* d_frames, int nframe
   if (!types || ntypes < 1 || ntypes > 8) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": bad feature type list");
   bool want_orb = false, want_sift = false, want_surf = false;
   for (int i = 0; i < ntypes; i++) {
-    if (types[i] == EVH_FEATURE_ORB) want_orb = true;
-    else if (types[i] == EVH_FEATURE_SIFT) want_sift = true;
-    else if (types[i] == EVH_FEATURE_SURF) want_surf = true;
-    else return evh_fail(c, EVH_ERR_INVALID, "unknown feature type");
+    // the concatenation buffer holds one segment per detector (kcap + sift_cap + surf_cap rows): a type named twice would
+    // overflow it, so it is refused (the reference would simply match the same key points twice and deduplicate them)
+    bool* seen = types[i] == EVH_FEATURE_ORB ? &want_orb : types[i] == EVH_FEATURE_SIFT ? &want_sift :
+                 types[i] == EVH_FEATURE_SURF ? &want_surf : nullptr;
+    if (!seen) return evh_fail(c, EVH_ERR_INVALID, "unknown feature type");
+    if (*seen) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": a feature type appears twice in the list");
+    *seen = true;
   }
   if (want_sift && !c->sift_cap) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": SIFT in the list needs evh_sift_enable");
   if (want_surf && !c->surf_cap) return evh_fail(c, EVH_ERR_INVALID, std::string(who) + ": SURF in the list needs evh_surf_enable");
@@ -416,7 +419,7 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
   // ~5 KB of static arrays (both opt in to more than the default 64 KB at launch)
   if ((size_t)c->kcap * 5 * sizeof(int) > 150 * 1024 || 8 * ((size_t)EVH_K1CAP + c->kcap) + 8 * 1024 > 160 * 1024) {
     delete c;
-    return evh_fail(nullptr, EVH_ERR_CAPACITY, "evh_create: max_features too large for the LDS lists of the matching filter / key-point selection (<= 6000)");
+    return evh_fail(nullptr, EVH_ERR_CAPACITY, "evh_create: max_features too large for the LDS lists of the matching filter / key-point selection (<= EVH_MAX_FEATURES = 5984)");
   }
   int rc = EVH_SUCCESS;
   auto fail = [&](int code) { g_create_error = c->err; evh_destroy(c); return code; };

@@ -51,7 +51,9 @@ class KeyPoints:
         nq, nt = len(q), len(t)
         if nq == 0 or nt == 0:
             raise NoMatchesException("len(matches) 0 < min_matching_pts {}".format(min_matching_pts), "couldn't process")
-        ctx = runtime.get_context(64, 64, 2, max(nq, nt, runtime.NFEATURES))
+        # the uint8 2-NN / filter work on a frame slot's rows (context capacity); the float forms (SIFT / SURF: up to 65 535
+        # rows per frame) take any row count, so they do not size the context
+        ctx = runtime.get_context(64, 64, 2, runtime.NFEATURES if float_desc else max(nq, nt, runtime.NFEATURES))
         dev = runtime.device()
         idx = torch.empty(nq, 2, dtype=torch.int32, device=dev)
         d2 = torch.empty(nq, 2, dtype=torch.float32 if float_desc else torch.int32, device=dev)
@@ -82,6 +84,12 @@ class KeyPoints:
         """-> (static_pts_a, static_pts_b) float32[M,2] arrays (matching.py:152-163)."""
         import torch
         ctx, rows = self._match_rows(acceding_kps, LOWES_RATIO, MINIMUM_MATCHING_POINTS)
+        slot = ctx.lib.evh_orb_capacity(ctx.h)
+        if len(rows) > slot * ctx.max_frames:
+            # evh_find_homography_ransac / evh_static_filter view the context's per-pair buffers as one problem of up to
+            # (rows per frame slot) x (frame slots) rows: a pair with more matches (SIFT at 720p: ~15 000) gets a context with
+            # enough slots -- the reference has no bound here (matching.py:152-163)
+            ctx = runtime.get_context(64, 64, -(-len(rows) // slot) + 1, ctx.max_features)
         H, _, _ = ctx.find_homography(rows, thr=reproj_thresh)
         if H is None:
             raise NoMatchesException("can't find homography matrix", "couldn't process")

@@ -97,20 +97,26 @@ def get_homography_dict(capture, resize_width=400, matching_path=None, none_H_pr
         from .._lib import Context
         if cuda:
             torch.cuda.synchronize(dev)
+        from .._lib import MAX_FEATURES
+        # every list grows from what the context that overflowed actually had, each up to its own limit
         feats = max(ctx.max_features, nfeatures)
+        sift0 = max(ctx.lib.evh_sift_capacity(ctx.h), runtime.sift_features_for(dw, dh)) if "SIFT" in features else 0
+        surf0 = max(ctx.lib.evh_surf_capacity(ctx.h), runtime.surf_features_for(dw, dh)) if "SURF" in features else 0
         grow = 1
         while True:
-            feats *= 2
+            at_limit = feats >= MAX_FEATURES and (not sift0 or sift0 * grow >= runtime.TYPE_FEATURES_MAX) and \
+                (not surf0 or surf0 * grow >= runtime.TYPE_FEATURES_MAX)
+            feats = min(feats * 2, MAX_FEATURES)
             grow *= 2
             try:
-                if grow > 16:
+                if at_limit:
                     raise EvhError("giving up")
                 big = Context(device=runtime.device_index(), max_w=max(dw, 64), max_h=max(dh, 64),
-                              max_features=min(feats, 6000), max_frames=chunk_frames)
-                if "SIFT" in features:
-                    big.sift_enable(min(runtime.TYPE_FEATURES_MAX, runtime.sift_features_for(dw, dh) * grow))
-                if "SURF" in features:
-                    big.surf_enable(min(runtime.TYPE_FEATURES_MAX, runtime.surf_features_for(dw, dh) * grow))
+                              max_features=feats, max_frames=chunk_frames)
+                if sift0:
+                    big.sift_enable(min(runtime.TYPE_FEATURES_MAX, sift0 * grow))
+                if surf0:
+                    big.surf_enable(min(runtime.TYPE_FEATURES_MAX, surf0 * grow))
             except EvhError:
                 raise EvhError("frame %d..%d: more key points (ORB ties at the retainBest cut, or SIFT key points) than "
                                "the largest frame slot this device path supports" % (frame_no[0], frame_no[0] + nb - 1))

@@ -137,6 +137,8 @@ int evh_set_fast_lift(evh_ctx* ctx, int on);
  * EVH_ORDER_CANONICAL: every tie at the cut kept, key points in (level, y, x) order (rounds 1-3); faster (lifting applies),
  *   H agrees with the reference only where RANSAC's consensus does not depend on the draw. */
 enum { EVH_ORDER_CANONICAL = 0, EVH_ORDER_OPENCV = 1 };
+/* largest max_features evh_create accepts (the matching filter keeps five lists of a frame slot's rows in LDS) */
+#define EVH_MAX_FEATURES 5984
 int evh_set_keypoint_order(evh_ctx* ctx, int mode);
 int evh_get_keypoint_order(const evh_ctx* ctx);
 /* The pair / stream entries below additionally let the second frame of a pair -- every other frame of a stream --

@@ -173,9 +173,9 @@ def test_multi_type_stream_vs_oracle(features):
 def test_multi_type_fixed_iteration_forms_agree(monkeypatch):
     """The fixed-iteration mode through the multi-type path: RANSAC #1 of every type and the scan spread their samples over
     workgroups (k_static_hyp / k_scan_hyp + the finishing kernels, 1 000-2 000 rows per pair here, so the four-wave
-    refinement passes run too).  No oracle form of this combination exists; the spread form must equal the
-    single-workgroup kernels (EVH_SCAN_ONE_WG=1), which the ORB tests pin against the oracle, bit for bit -- also with a
-    short hypothesis table (EVH_SCAN_CHUNKS=5: the rest of the samples inside the finishing kernels)."""
+    refinement passes run too).  Every form -- the single-workgroup kernels (EVH_SCAN_ONE_WG=1), the spread form, and the
+    spread form with a short hypothesis table (EVH_SCAN_CHUNKS=5: the rest of the samples inside the finishing kernels) --
+    against the oracle's fixed-iteration multi-type stream (evo_stream_gray_types_ex, force_max = 1)."""
     w, h = 400, 224
     frames, _ = S.make_stream(33, 4, w, h)
     n = len(frames) - 1
@@ -191,9 +191,12 @@ def test_multi_type_fixed_iteration_forms_agree(monkeypatch):
             c.stream_homography_batch_types(dev(frames), H, st, ["SIFT", "ORB"], force_max_iters=True)
             c.synchronize()
             outs.append((H.cpu().numpy(), st.cpu().numpy()))
-        assert list(outs[0][1]) == [0] * n
+        Ho, so, rc = O.stream_gray_types(frames, ["SIFT", "ORB"], force_max_iters=True)
+        assert rc == -1 and list(so) == [0] * n
+        for H, st in outs:
+            assert np.array_equal(st, so) and np.allclose(H.reshape(-1, 3, 3), Ho, rtol=1e-9, atol=1e-12)
         for H, st in outs[1:]:
-            assert np.array_equal(st, outs[0][1]) and np.array_equal(H, outs[0][0])
+            assert np.array_equal(H, outs[0][0])
     finally:
         c.close()
 
@@ -280,6 +283,42 @@ def test_python_mirror_sift_and_type_list():
     got = np.array([d[k]["H"] for k in range(2, len(frames) + 1)])
     assert rc == -1 and (ss == 0).all() and np.allclose(got, Hs, rtol=1e-9, atol=1e-12)
     runtime.reset()
+
+
+def test_mirror_matches_more_float_rows_than_a_context_holds():
+    """KeyPoints.match_kps / match_static_kps on SIFT rows of a 720p frame (more than EVH_MAX_FEATURES = 5984 per frame): the
+    float 2-NN and filter take any row count, so the mirror must not size the context by it (the reference has no bound,
+    matching.py:75-163); the context is sized by the MATCHES that reach findHomography."""
+    from evenvizion_amd import runtime
+    from evenvizion_amd._lib import MAX_FEATURES
+    from evenvizion_amd.processing import KeyPoints
+    runtime.reset()
+    prev, cur, _ = S.make_pair(91, 1280, 720)
+    o1, o0 = O.sift_detect(cur, cap=65535), O.sift_detect(prev, cap=65535)
+    assert len(o1["xy"]) > MAX_FEATURES and len(o0["xy"]) > MAX_FEATURES
+    pa, pb = KeyPoints(o1["xy"], o1["desc"]).match_kps(KeyPoints(o0["xy"], o0["desc"]))
+    oi, od = O.knn2_f32(o1["desc"], o0["desc"])
+    mq, mt = O.ratio_unique_f32(oi, od)
+    wa, wb = O.remove_double(o1["xy"][mq], o0["xy"][mt])
+    assert len(pa) > 500 and np.array_equal(np.array(pa), wa) and np.array_equal(np.array(pb), wb)
+    sa, sb = KeyPoints(o1["xy"], o1["desc"]).match_static_kps(KeyPoints(o0["xy"], o0["desc"]))
+    st, ea, eb = O.match_static_f32(o1["xy"], o1["desc"], o0["xy"], o0["desc"])
+    assert st == 0 and np.array_equal(sa, ea) and np.array_equal(sb, eb)
+    runtime.reset()
+
+
+def test_a_feature_type_named_twice_is_refused():
+    from evenvizion_amd._lib import Context, EvhError
+    frames, _ = S.make_stream(5, 3, 400, 224)
+    c = Context(device=0, max_w=400, max_h=224, max_features=500, max_frames=4)
+    try:
+        c.sift_enable(4096)
+        H = torch.zeros(2, 9, dtype=torch.float64, device="cuda")
+        st = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+        with pytest.raises(EvhError):
+            c.stream_homography_batch_types(torch.from_numpy(frames).cuda(), H, st, ["SIFT", "ORB", "SIFT"])
+    finally:
+        c.close()
 
 
 # ---- SURF (frame_processing.py:65-67) ---------------------------------------------------------------------------------

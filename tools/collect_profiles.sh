@@ -8,6 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export EVH_BENCH_CACHE=/tmp/evh_bench_cache     # the 64 synthetic pairs are generated once (in parallel, outside the profiler)
 (cd $R && python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --skip-no-temporal > $O/prime.json 2> $O/prime.err)
+(cd $R && python bench.py --config 3 --steps 1 --warmup 1 --cpu-pairs 0 > $O/prime3.json 2> $O/prime3.err)   # primes the config-3 cache outside the profiler
 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --gen-procs 1 --unique 64 --skip-no-temporal > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/write.log 2>&1
@@ -16,7 +17,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 # when the three do not fit one pass -- then the calibrated factor of profiles/r03_fetch_calibration.txt stands alone
 (rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/rdreq -o rdreq --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --unique 64 --skip-no-temporal > $O/rdreq.log 2>&1 || true)
 # the stream workload (BASELINE configs[2]): kernel stats only
-rocprofv3 --kernel-trace --stats -d $O/stats3 -o stats3 --output-format csv -- python3 $R/bench.py --config 3 --steps 4 --warmup 1 --cpu-pairs 0 > $O/stats3.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats3 -o stats3 --output-format csv -- python3 $R/bench.py --config 3 --steps 4 --warmup 1 --cpu-pairs 0 --gen-procs 1 > $O/stats3.log 2>&1
 cd $R && python bench.py > $O/bench.json 2> $O/bench.err
 for c in 2 3 4 5; do python bench.py --config $c > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err || true; done
 python bench.py --config 3 --force-max-iters > $O/bench_cfg3_forced.json 2> $O/bench_cfg3_forced.err || true
