@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(os.path.dirname(_HERE), "libevcap.so")
+_SO = os.environ.get("EVCAP_SO") or os.path.join(os.path.dirname(_HERE), "libevcap.so")   # override: sanitizer builds
 
 BGR_SWSCALE_X86 = 0
 BGR_SWSCALE_C = 1

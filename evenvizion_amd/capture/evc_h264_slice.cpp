@@ -328,14 +328,14 @@ struct MbDecoder {
         int x = raster & 3, y = raster >> 2;
         int cls = (!(x & 1) && !(y & 1)) ? 0 : ((x & 1) && (y & 1) ? 1 : 2);
         int ls = 16 * kNormAdjust4x4[q % 6][cls];
-        if (q >= 24) return (level * ls) << (q / 6 - 4);
+        if (q >= 24) return (level * ls) * (1 << (q / 6 - 4));
         return (level * ls + (1 << (3 - q / 6))) >> (4 - q / 6);
     }
     static int dq8(int level, int q, int raster) {
         static const uint8_t cls[16] = {0, 3, 4, 3, 3, 1, 5, 1, 4, 5, 2, 5, 3, 1, 5, 1};
         int x = raster & 7, y = raster >> 3;
         int ls = 16 * kNormAdjust8x8[q % 6][cls[((y & 3) << 2) | (x & 3)]];
-        if (q >= 36) return (level * ls) << (q / 6 - 6);
+        if (q >= 36) return (level * ls) * (1 << (q / 6 - 6));
         return (level * ls + (1 << (5 - q / 6))) >> (6 - q / 6);
     }
 
@@ -369,7 +369,7 @@ struct MbDecoder {
                     for (int r = 0; r < 4; ++r) {
                         int v = f[r];
                         if (qp >= 36)
-                            v = (v * ls) << (qp / 6 - 6);
+                            v = (v * ls) * (1 << (qp / 6 - 6));
                         else
                             v = (v * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
                         dcl[r * 4 + col] = v;  // block at column `col`, row `r`
@@ -437,7 +437,7 @@ struct MbDecoder {
                     int a = lev[0], b = lev[1], cc_ = lev[2], d = lev[3];
                     int f[4] = {a + b + cc_ + d, a - b + cc_ - d, a + b - cc_ - d, a - b - cc_ + d};
                     int ls = 16 * kNormAdjust4x4[q % 6][0];
-                    for (int i = 0; i < 4; ++i) dcc[comp][i] = ((f[i] * ls) << (q / 6)) >> 5;
+                    for (int i = 0; i < 4; ++i) dcc[comp][i] = ((f[i] * ls) * (1 << (q / 6))) >> 5;
                 }
             }
             for (int comp = 0; comp < 2; ++comp)

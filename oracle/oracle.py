@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libevz_oracle.so")
+_SO = os.environ.get("EVZ_ORACLE_SO") or os.path.join(_HERE, "libevz_oracle.so")   # override: instrumented builds (tools/hygiene.sh)
 
 OK, NO_DESCRIPTORS, FEW_MATCHES, NO_PROVISIONAL_H, LOW_INLIER_RATIO, NO_FINAL_H = range(6)
 

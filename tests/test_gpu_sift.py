@@ -85,6 +85,38 @@ def test_sift_flat_and_tiny_frames():
         c.close()
 
 
+def test_rare_exit_inputs_sift_and_surf():
+    """The inputs of tools/hygiene_inputs.py (chosen so that the rarely taken exits of the SIFT / SURF statements are taken:
+    singular and near-singular refinement systems, refinement leaving the layer range or the border or not converging, blobs
+    at the border, windows larger than the image, flat and saturated content; profiles/r04_hygiene.txt lists the execution
+    counts on the oracle's side) through the device kernels: key points, order, descriptors bit for bit."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("hygiene_inputs", os.path.join(os.path.dirname(__file__), "..", "tools", "hygiene_inputs.py"))
+    hy = importlib.util.module_from_spec(spec); spec.loader.exec_module(hy)
+    for img in hy.detector_inputs():
+        h, w = img.shape
+        if w < 64 or h < 64:
+            continue
+        c = make_ctx(w, h, frames=2, sift=16384)
+        try:
+            c.surf_enable(8192)
+            c.sift_detect_batch(dev(np.stack([img, img])))
+            o = O.sift_detect(img, cap=65536)
+            if len(o["xy"]) == 0:
+                assert c.lib.evh_sift_count(c.h, 0) == 0
+            else:
+                _same_keypoints(c.sift_download(0), o)
+            c.surf_detect_batch(dev(np.stack([img, img])))
+            os_ = O.surf_detect(img)
+            if len(os_["xy"]) == 0:
+                assert c.lib.evh_surf_count(c.h, 0) == 0
+            else:
+                _same_surf(c.surf_download(0), os_)
+        finally:
+            c.close()
+
+
 def test_sift_capacity_is_flagged():
     from evenvizion_amd._lib import EvhError
     a, b, _ = S.make_pair(5, 400, 224)
