@@ -81,7 +81,7 @@ with open(os.path.join(out, tag + "_pmc_hbm_traffic.csv"), "w") as fo:
         fo.write("%s,%d,%.0f,%.0f,%.0f,%.0f\n" % (k, n, fb, FETCH_CORRECTION * fb, wb, ex))
 
 # traffic.json: dominant group = FAST (sample + main [+ redo]) per step
-steps = max(len(fetch.get("k_fast_main", [])), 1)
+steps = max(len(fetch.get("k_fast_main", [])), len(fetch.get("k_fast", [])), 1)   # k_fast: the dense kernel of the reference key-point order
 fast_fetch = fast_write = 0.0
 for k in ("k_fast_sample", "k_fast_main", "k_fast_redo", "k_fast_thr", "k_fast_verify", "k_fast", "k_fast_hint"):
     fast_fetch += 1024.0 * sum(fetch.get(k, [])) / steps
@@ -123,7 +123,7 @@ if f:
 
     # VALU issue of the dominant (FAST) group per launch, for bench.py's informational "valu_issue" entry
     fast = [k for k in ("k_fast_sample", "k_fast_main", "k_fast_redo", "k_fast") if k in agg]
-    launches = float(max(len(disp.get("k_fast_main", ())), 1))
+    launches = float(max(len(disp.get("k_fast_main", ())), len(disp.get("k_fast", ())), 1))
     insts = sum(agg[k]["SQ_INSTS_VALU"] for k in fast) / launches
     if insts > 0:
         json.dump({"fast@1280x720x1024_n500_c3": {"valu_wave_insts_per_launch": int(insts),
