@@ -83,6 +83,9 @@ def parse_args():
     ap.add_argument("--order", choices=["reference", "canonical"], default="reference",
                     help="ORB key-point order (include/evhip.h evh_set_keypoint_order): reference = OpenCV 3.4.2 on libstdc++, what the "
                          "reference's recorded run agrees with (default); canonical = all ties, (level, y, x) order, FAST threshold lifting applies")
+    ap.add_argument("--solver", choices=["exact", "fast"], default="exact",
+                    help="LM's 8x8 systems: exact = the operator's Jacobi eigen-solve (H bit-identical to the oracle, default); fast = LDL^T "
+                         "(include/evhip.h evh_set_solver_mode: frame corners within ~1e-3 px of the exact mode)")
     ap.add_argument("--skip-no-temporal", action="store_true", help="do not time the extra no-temporal loop (profiling runs: every launch of the run is then the same workload)")
     ap.add_argument("--gen-procs", type=int, default=0, help="host processes that generate the synthetic pairs (0 = auto; use 1 under rocprofv3: no child processes)")
     ap.add_argument("--sync-solve", action="store_true",
@@ -324,6 +327,7 @@ def main():
     set_temporal(not args.no_temporal)
     for c_ in ctxs:
         c_.set_keypoint_order(1 if args.order == "reference" else 0)
+        c_.set_solver_mode(1 if args.solver == "fast" else 0)
     for _ in range(max(args.warmup, NCTX)):
         step()
     torch.cuda.synchronize(dev)
@@ -378,6 +382,19 @@ def main():
         canonical_order_value = round(pairs_per_step * co_steps / timed(co_steps), 2)
         for c_ in ctxs:
             c_.set_keypoint_order(1)
+
+    # the same loop with the tolerance-mode solver (LDL^T for LM's 8x8 systems): what a caller who accepts frame corners within
+    # ~1e-3 px of the operator's own arithmetic gets; reported next to the headline, which stays on the exact solver
+    fast_solver_value = None
+    if args.solver == "exact" and not args.skip_no_temporal:
+        for c_ in ctxs:
+            c_.set_solver_mode(1)
+        for _ in range(2):
+            step()
+        fs_steps = max(2, min(args.steps, 10))
+        fast_solver_value = round(pairs_per_step * fs_steps / timed(fs_steps), 2)
+        for c_ in ctxs:
+            c_.set_solver_mode(0)
 
     # ---- roofline of the dominant kernel group --------------------------------------------------------------------
     per_frame, per_pair = algorithmic_bytes(w, h, nfeat, args.channels)
@@ -527,6 +544,7 @@ def main():
                        "no_temporal_value": no_temporal_value,
                        "keypoint_order": "OpenCV 3.4.2 retainBest on libstdc++ nth_element/partition (the reference's; every FAST corner at threshold 20 is scored)" if args.order == "reference" else "canonical (all ties, level/y/x)",
                        "canonical_order_value": canonical_order_value,
+                       "lm_solver": args.solver, "fast_solver_value": fast_solver_value,
                        "arithmetic": "u8/i32 pixels+descriptors, f32 Harris+reprojection, f64 DLT+LM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

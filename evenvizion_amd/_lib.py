@@ -17,6 +17,7 @@ EVH_SUCCESS = 0
 PAIR_OK, PAIR_NO_DESCRIPTORS, PAIR_FEW_MATCHES, PAIR_NO_PROVISIONAL_H, PAIR_LOW_INLIER_RATIO, PAIR_NO_FINAL_H, \
     PAIR_CAPACITY = range(7)
 ORDER_CANONICAL, ORDER_OPENCV = 0, 1
+SOLVER_EXACT, SOLVER_FAST = 0, 1
 MAX_FEATURES = 5984   # EVH_MAX_FEATURES (include/evhip.h): largest max_features a context accepts
 MODE_INDEPENDENT_PAIRS, MODE_STREAM = 0, 1
 
@@ -43,6 +44,8 @@ SIGNATURES = {
     "evh_orb_detect_batch_resized": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i]),
     "evh_stream_homography_batch_resized": (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _d, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "evh_set_fast_lift": (_i, [_vp, _i]),
+    "evh_set_solver_mode": (_i, [_vp, _i]),
+    "evh_get_solver_mode": (_i, [_vp]),
     "evh_set_keypoint_order": (_i, [_vp, _i]),
     "evh_get_keypoint_order": (_i, [_vp]),
     "evh_set_fast_share": (_i, [_vp, _i]),
@@ -208,6 +211,14 @@ class Context:
 
     def set_fast_lift(self, on=True):
         self._check(self.lib.evh_set_fast_lift(self.h, int(bool(on))))
+
+    def set_solver_mode(self, mode):
+        """SOLVER_EXACT (default): LM's 8x8 systems by the operator's Jacobi eigen-solve (H bit-identical to the oracle);
+        SOLVER_FAST: by LDL^T (stream pairs ~45 % cheaper; H within ~1e-3 px of the exact mode's, see include/evhip.h)."""
+        self._check(self.lib.evh_set_solver_mode(self.h, int(mode)))
+
+    def get_solver_mode(self):
+        return int(self.lib.evh_get_solver_mode(self.h))
 
     def set_keypoint_order(self, mode):
         """ORDER_OPENCV (default): key points leave retainBest in the order (and set) OpenCV 3.4.2 on libstdc++ leaves them --

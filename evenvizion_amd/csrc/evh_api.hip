@@ -152,6 +152,7 @@ int ensure_lane_scratch(evh_ctx* c) {
 
 EvhRansacArgs pair_ransac_args(evh_ctx* c, double thr, int max_iters, double conf, int force_max) {
   EvhRansacArgs R{};
+  R.fast_solver = c->solver_mode;
   if (force_max && ensure_lane_scratch(c) == EVH_SUCCESS) R.lane_v = c->d_lane_v;
   R.pts = c->d_pts; R.pts2 = c->d_pts2; R.row_stride = c->kcap; R.npts = c->d_npts; R.npts2 = c->d_npts2;
   R.status = c->d_pstatus; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = force_max;
@@ -299,6 +300,7 @@ int ensure_multitype(evh_ctx* c) {
 
 EvhRansacArgs mt_ransac_args(evh_ctx* c, double thr, int max_iters, double conf, int force_max) {
   EvhRansacArgs R{};
+  R.fast_solver = c->solver_mode;
   if (force_max && ensure_lane_scratch(c) == EVH_SUCCESS) R.lane_v = c->d_lane_v;
   const EvhPairBufs& B = c->mt;
   R.pts = B.pts; R.pts2 = B.pts2; R.row_stride = B.cap; R.npts = B.npts; R.npts2 = B.npts2;
@@ -524,6 +526,14 @@ int evh_set_fast_lift(evh_ctx* c, int on) {
   c->fast_lift = on != 0;
   return EVH_SUCCESS;
 }
+
+int evh_set_solver_mode(evh_ctx* c, int mode) {
+  if (!c || (mode != EVH_SOLVER_EXACT && mode != EVH_SOLVER_FAST)) return EVH_ERR_INVALID;
+  c->solver_mode = mode;
+  return EVH_SUCCESS;
+}
+
+int evh_get_solver_mode(const evh_ctx* c) { return c ? c->solver_mode : EVH_ERR_INVALID; }
 
 int evh_set_keypoint_order(evh_ctx* c, int mode) {
   if (!c || (mode != EVH_ORDER_CANONICAL && mode != EVH_ORDER_OPENCV)) return EVH_ERR_INVALID;
@@ -816,6 +826,7 @@ static int find_homography_entry(evh_ctx* c, const float* d_pts, int n, double t
   { int jr = join_solve(c); if (jr) return jr; }
   // scratch: the per-pair buffers viewed as one big problem
   EvhRansacArgs R{};
+  R.fast_solver = c->solver_mode;
   R.pts = const_cast<float*>(d_pts); R.n_fixed = n; R.thr = thr; R.max_iters = max_iters; R.conf = conf; R.force_max = force_max;
   if (force_max) { int lr = ensure_lane_scratch(c); if (lr) return lr; R.lane_v = c->d_lane_v; }
   R.mask = c->d_mask; R.crow = c->d_crow; R.lm = c->d_lm;

@@ -1532,18 +1532,18 @@ struct SelCvArgs {
   const uint32_t* tdesc;     // [nframes][total_tiles][8] tile burst descriptors written by k_fast
   int total_tiles;
   int heap_cap;              // entries of the dynamic LDS heap (>= 2 * largest quota + 1)
+  int level0, nlev;          // this launch handles levels level0 .. level0 + nlev - 1
   int phase_limit;           // profiling aid: 1 = stop after the row-major sequence, 2 = after the first retainBest, 0 = all
 };
 
 struct CvLds {
-  int wsumL[4], wsumR[4];
-  int bc[8];
-  unsigned long long tmp[4];
+  int wsumL[16], wsumR[16];   // up to 16 waves per workgroup (k_select_cv runs with 256 or 1024 threads)
+  int bc[16];
 };
 
 #define CV_NOPOS 0x7FFFFFFF
 
-// exclusive prefix of (a, b) over the 256 threads of the workgroup; totals come back in ta / tb.  Two barriers.
+// exclusive prefix of (a, b) over the threads of the workgroup (blockDim.x = 64 * NW); totals come back in ta / tb.  Two barriers.
 __device__ __forceinline__ void cv_scan2(CvLds& S, int a, int b, int& ea, int& eb, int& ta, int& tb) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int ia = a, ib = b;
@@ -1555,9 +1555,13 @@ __device__ __forceinline__ void cv_scan2(CvLds& S, int a, int b, int& ea, int& e
   if (lane == 63) { S.wsumL[wv] = ia; S.wsumR[wv] = ib; }
   __syncthreads();
   int ba = 0, bb = 0;
-  for (int w = 0; w < wv; w++) { ba += S.wsumL[w]; bb += S.wsumR[w]; }
-  ta = S.wsumL[0] + S.wsumL[1] + S.wsumL[2] + S.wsumL[3];
-  tb = S.wsumR[0] + S.wsumR[1] + S.wsumR[2] + S.wsumR[3];
+  ta = 0; tb = 0;
+  const int nw = (int)blockDim.x >> 6;
+  for (int w = 0; w < nw; w++) {
+    const int l_ = S.wsumL[w], r_ = S.wsumR[w];
+    if (w < wv) { ba += l_; bb += r_; }
+    ta += l_; tb += r_;
+  }
   ea = ba + ia - a;
   eb = bb + ib - b;
   __syncthreads();
@@ -1570,9 +1574,9 @@ __device__ __forceinline__ void cv_scan2(CvLds& S, int a, int b, int& ea, int& e
 template <int MODE, class EP, class LP>
 __device__ int cv_partition(EP a, int lo, int hi, uint32_t p, LP lpos, LP rpos, CvLds& S) {
   typedef typename std::remove_pointer<LP>::type PT;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, NT = (int)blockDim.x, NW = NT >> 6;
   int cntL = 0, cntR = 0;
-  for (int base = lo; base < hi; base += 1024) {
+  for (int base = lo; base < hi; base += 4 * NT) {
     const int i0 = base + 4 * tid;
     uint32_t fl = 0, fr = 0;
 #pragma unroll
@@ -1596,18 +1600,19 @@ __device__ int cv_partition(EP a, int lo, int hi, uint32_t p, LP lpos, LP rpos, 
     cntR += tr;
   }
   __syncthreads();   // lists complete
-  // number of pairs: the largest m with L[k] < R[k] for all k < m (monotone), by 256-way search; R[k] = rpos[cntR - 1 - k]
+  // number of pairs: the largest m with L[k] < R[k] for all k < m (monotone), by NT-way search; R[k] = rpos[cntR - 1 - k]
   const int K = min(cntL, cntR);
   int lo_k = 0, hi_k = K;   // invariant: pairs [0, lo_k) swap, pairs [hi_k, K) do not
   while (hi_k > lo_k) {
     const int span = hi_k - lo_k;
-    const int step = (span + 255) / 256;
+    const int step = (span + NT - 1) / NT;
     const int k = lo_k + tid * step;
     const bool ok = k < hi_k && (int)lpos[k] < (int)rpos[cntR - 1 - k];
     const unsigned long long bal = __ballot(ok);
     if ((tid & 63) == 0) S.bc[tid >> 6] = __popcll(bal);
     __syncthreads();
-    const int good = S.bc[0] + S.bc[1] + S.bc[2] + S.bc[3];   // probes are monotone: the first `good` probes hold
+    int good = 0;                                             // probes are monotone: the first `good` probes hold
+    for (int w = 0; w < NW; w++) good += S.bc[w];
     __syncthreads();
     if (good == 0) { hi_k = lo_k; break; }
     const int last_good = lo_k + (good - 1) * step;
@@ -1615,7 +1620,7 @@ __device__ int cv_partition(EP a, int lo, int hi, uint32_t p, LP lpos, LP rpos, 
     hi_k = min(hi_k, last_good + step);
   }
   const int m = lo_k;
-  for (int k = tid; k < m; k += 256) {
+  for (int k = tid; k < m; k += NT) {
     const int i = (int)lpos[k], j = (int)rpos[cntR - 1 - k];
     const unsigned long long t = a[i];
     a[i] = a[j];
@@ -1664,8 +1669,8 @@ __device__ void cv_adjust_heap(unsigned long long* hp, int hole, int len, unsign
 // step, the next element that beats the heap's top found by ballot), the heap operations are one thread's.
 template <class EP>
 __device__ void cv_heap_select(EP a, int first, int middle, int last, unsigned long long* hp, CvLds& S) {
-  const int tid = threadIdx.x, len = middle - first;
-  for (int i = tid; i < len; i += 256) hp[i] = a[first + i];
+  const int tid = threadIdx.x, len = middle - first, NT = (int)blockDim.x, NW = NT >> 6;
+  for (int i = tid; i < len; i += NT) hp[i] = a[first + i];
   __syncthreads();
   if (tid == 0 && len >= 2) {
     int parent = (len - 2) / 2;
@@ -1677,7 +1682,7 @@ __device__ void cv_heap_select(EP a, int first, int middle, int last, unsigned l
     }
   }
   __syncthreads();
-  for (int base = middle; base < last; base += 256) {
+  for (int base = middle; base < last; base += NT) {
     const int idx = base + tid;
     const unsigned long long mine = idx < last ? a[idx] : 0ull;
     int done = base;   // elements of this chunk below `done` have been handled
@@ -1687,9 +1692,10 @@ __device__ void cv_heap_select(EP a, int first, int middle, int last, unsigned l
       const unsigned long long bal = __ballot(hit);
       if ((tid & 63) == 0) S.bc[tid >> 6] = bal ? (int)(tid + __ffsll((long long)bal) - 1) : 1 << 20;
       __syncthreads();
-      const int j = min(min(S.bc[0], S.bc[1]), min(S.bc[2], S.bc[3]));   // thread index of the first hit
+      int j = 1 << 20;                                                   // thread index of the first hit
+      for (int w = 0; w < NW; w++) j = min(j, S.bc[w]);
       __syncthreads();
-      if (j >= 256) break;
+      if (j >= NT) break;
       if (tid == j) {
         // __pop_heap(first, middle, result = a + idx)
         a[idx] = top;
@@ -1699,7 +1705,7 @@ __device__ void cv_heap_select(EP a, int first, int middle, int last, unsigned l
       __syncthreads();
     }
   }
-  for (int i = tid; i < len; i += 256) a[first + i] = hp[i];
+  for (int i = tid; i < len; i += NT) a[first + i] = hp[i];
   __syncthreads();
 }
 
@@ -1720,11 +1726,11 @@ __device__ bool cv_introselect_loop(EP a, int first, int nth, int last, int dept
   while (last - first > 3) {
     if constexpr (std::is_same<LP, uint32_t*>::value) if (sm && last - first <= CV_SMALL) {   // (the LDS instantiation never stages)
       const int len = last - first;
-      for (int i = threadIdx.x; i < len; i += 256) sm->a[i] = a[first + i];
+      for (int i = threadIdx.x; i < len; i += (int)blockDim.x) sm->a[i] = a[first + i];
       __syncthreads();
       const bool ok = cv_introselect_loop<unsigned long long*, uint16_t*>(sm->a, 0, nth - first, len, depth, sm->l, sm->r, S, hp,
                                                                            hp_cap, nullptr);
-      for (int i = threadIdx.x; i < len; i += 256) a[first + i] = sm->a[i];
+      for (int i = threadIdx.x; i < len; i += (int)blockDim.x) a[first + i] = sm->a[i];
       __syncthreads();
       return ok;
     }
@@ -1782,13 +1788,13 @@ __device__ int cv_retain_best(unsigned long long* a, int n, int npoints, uint32_
   if (npoints == 0) return 0;
   const int depth = 2 * (31 - __clz(n));
   if (n <= CV_SMALL) {                       // everything in LDS, the survivors copied back
-    for (int i = threadIdx.x; i < n; i += 256) sm->a[i] = a[i];
+    for (int i = threadIdx.x; i < n; i += (int)blockDim.x) sm->a[i] = a[i];
     __syncthreads();
     if (!cv_introselect_loop<unsigned long long*, uint16_t*>(sm->a, 0, npoints, n, depth, sm->l, sm->r, S, hp, hp_cap, nullptr))
       return -1;
     const uint32_t amb = (uint32_t)(sm->a[npoints - 1] >> 32);
     const int k = cv_partition<1>(sm->a, npoints, n, amb, sm->l, sm->r, S);
-    for (int i = threadIdx.x; i < k; i += 256) a[i] = sm->a[i];
+    for (int i = threadIdx.x; i < k; i += (int)blockDim.x) a[i] = sm->a[i];
     __syncthreads();
     return k;
   }
@@ -1801,15 +1807,18 @@ __device__ __forceinline__ float f32_from_order_key(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-__global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
+// Launched twice: the large pyramid levels with 1024 threads per workgroup (a partition pass is a chain of steps, each a
+// load + a workgroup scan + stores: four times the threads = a quarter of the steps), the small ones with 256.
+__global__ __launch_bounds__(1024) void k_select_cv(SelCvArgs B) {
   const SelectArgs& A = B.s;
   __shared__ CvLds S;
   __shared__ CvSmall SM;
   extern __shared__ unsigned long long cv_heap[];   // 2 * quota(level 0) + 2 entries
   int l, f;
   xcd_order(l, f);
-  if (f >= A.nframes) return;
-  const int tid = threadIdx.x;
+  if (f >= A.nframes || l >= B.nlev) return;
+  l += B.level0;
+  const int tid = threadIdx.x, NT = (int)blockDim.x, NW = NT >> 6;
   const EvhLevel L = A.lv[l];
   const uint32_t* cand = A.cand + (int64_t)f * A.cand_frame_entries + L.cand_off;
   const int n_raw = A.cand_count[f * EVH_NLEVELS + l];
@@ -1829,7 +1838,7 @@ __global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
     uint32_t* P = B.mask + (int64_t)f * 2 * B.mask_frame_words + B.mask_off[l];   // exclusive prefix in (tile row, row, tile column) order
     const uint32_t* td = B.tdesc + ((int64_t)f * B.total_tiles + L.tile_start) * 8;
     {
-      const int per = (NE + 255) / 256, e0 = tid * per, e1 = min(NE, e0 + per);
+      const int per = (NE + NT - 1) / NT, e0 = tid * per, e1 = min(NE, e0 + per);
       int sum = 0;
       for (int e = e0; e < e1; e++) {
         const int tx = e % TX, rr = e / TX, r = rr % FT_H, ty = rr / FT_H;
@@ -1847,7 +1856,7 @@ __global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
     __syncthreads();
     {
       const int lane = tid & 63, wv = tid >> 6;
-      for (int t = wv; t < TX * TY; t += 4) {
+      for (int t = wv; t < TX * TY; t += NW) {
         const int ty = t / TX, tx = t - ty * TX;
         const uint32_t wd = lane < 8 ? td[t * 8 + lane] : 0u;
         const int base = (int)__shfl(wd, 0);
@@ -1882,7 +1891,7 @@ __global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
     if (B.phase_limit == 2) return;
     // ---- Harris response of the survivors, in place
     const uint8_t* img = A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off;
-    for (int j = tid; j < k1; j += 256) {
+    for (int j = tid; j < k1; j += NT) {
       const uint32_t c = (uint32_t)a[j];
       const float r = harris_response(img, L.stride, (int)(c & 0xFFFu), (int)((c >> 12) & 0xFFFu));
       a[j] = ((unsigned long long)f32_order_key(r) << 32) | c;
@@ -1892,7 +1901,7 @@ __global__ __launch_bounds__(256) void k_select_cv(SelCvArgs B) {
     k2 = cv_retain_best(a, k1, q, lpos, rpos, S, cv_heap, B.heap_cap, &SM);
     if (k2 < 0) { unsupported = true; k2 = 0; }
     if (k2 > A.kcap) { overflow = true; k2 = A.kcap; }
-    for (int j = tid; j < k2; j += 256) {
+    for (int j = tid; j < k2; j += NT) {
       const unsigned long long e = a[j];
       const int64_t o = ((int64_t)f * EVH_NLEVELS + l) * A.kcap + j;
       A.tmp_meta[o] = ((uint32_t)l << 24) | ((uint32_t)e & 0xFFFFFFu);
@@ -2248,7 +2257,21 @@ int evh_launch_select(evh_ctx* c, int nframes) {
     B.heap_cap = 2 * q0 + 2;
     B.tdesc = c->d_cv_tdesc; B.total_tiles = c->g.total_tiles;
     { const char* e = getenv("EVH_CV_PHASE"); B.phase_limit = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k_select_cv, xcd_grid(EVH_NLEVELS, nframes), dim3(256), sizeof(unsigned long long) * (size_t)B.heap_cap, c->stream, B);
+    // levels with many corners (>= ~8000 expected: area above 0.3 Mpx) on 1024 threads, the rest on 256
+    // (measured: 1024 threads for the large levels 10.6 ms against 6.4 ms with 256 everywhere -- a barrier over 16 waves costs
+    // more than the steps it saves; EVH_CV_SPLIT / EVH_CV_NT keep the experiment reachable)
+    int split = 0, nt_small = 256;
+    { const char* e = getenv("EVH_CV_SPLIT"); if (e) split = std::min(EVH_NLEVELS, std::max(0, atoi(e))); }
+    { const char* e = getenv("EVH_CV_NT"); if (e) nt_small = std::min(1024, std::max(64, atoi(e) & ~63)); }
+    const size_t heap_bytes = sizeof(unsigned long long) * (size_t)B.heap_cap;
+    if (split > 0) {
+      B.level0 = 0; B.nlev = split;
+      hipLaunchKernelGGL(k_select_cv, xcd_grid(split, nframes), dim3(1024), heap_bytes, c->stream, B);
+    }
+    if (split < EVH_NLEVELS) {
+      B.level0 = split; B.nlev = EVH_NLEVELS - split;
+      hipLaunchKernelGGL(k_select_cv, xcd_grid(EVH_NLEVELS - split, nframes), dim3(nt_small), heap_bytes, c->stream, B);
+    }
     EVH_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, c->stream, A);
     EVH_HIP(c, hipGetLastError());

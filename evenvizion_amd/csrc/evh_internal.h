@@ -100,6 +100,7 @@ struct evh_ctx {
   int* d_fast_redo = nullptr;     // [1 + max_frames*8] redo work list (count first)
   // key-point order of the reference (EVH_ORDER_OPENCV): work arrays of k_select_cv
   int order_mode = 1;             // EVH_ORDER_OPENCV
+  int solver_mode = 0;            // EVH_SOLVER_EXACT
   unsigned long long* d_cv_seq = nullptr;   // [max_frames][cand_frame_entries] key << 32 | candidate, row-major then permuted
   uint32_t* d_cv_lpos = nullptr;  // [max_frames][cand_frame_entries] stopper positions of the partition passes
   uint32_t* d_cv_rpos = nullptr;

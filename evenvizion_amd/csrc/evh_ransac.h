@@ -12,6 +12,7 @@ struct EvhRansacArgs {
   int* status;           // per pair status carried between phases
   int n_fixed;           // single-problem entry: number of rows
   double thr; int max_iters; double conf; int force_max;
+  int fast_solver;       // EVH_SOLVER_FAST: the 8x8 systems of the LM refinement by LDL^T instead of cv::solve(DECOMP_EIG)'s Jacobi sweeps
   const double* Hsup0;   // stream mode: superposition entering the batch (NULL = first pair of the stream)
   const double* Hprev0;  // stream mode: previous H entering the batch (NULL = none)
   double* state_out;     // stream mode: {H_sup, H_prev} after the last pair, f64[18] (may be NULL)

@@ -777,6 +777,7 @@ struct SolveLds {        // scratch of the single-problem stages (refit, LM): us
   double x[8], xd[8], v[8], d[8], D[8], tmpd[8], A8[64], Ap[64], Inv[64];
   double sc[8];          // scalars: S, Sd, lambda, lc, nu, rmax ...
   int ib[8];             // ints: proceed flags, counts
+  int fast;              // EvhRansacArgs::fast_solver (set by the kernels before any solve)
   double T[NL * TS];     // the 64-point tile
   double P2[NL / 2 + 2]; // lm_eval: squared residuals of a tile, summed per pair of points (+ the two terms of an odd last point)
 };
@@ -1078,6 +1079,82 @@ __device__ __forceinline__ double dot8(const double* a, const double* b) {
 // S.sc: 0 = S, 1 = rmax of the kept point, 2 = lambda, 3 = lc, 4 = nu, 5 = Sd, 6 = rmax of the trial point
 // evalJ(): the pass WITH the Jacobian at S.x into S.sc[0], S.sc[1], S.A8, S.v -- lm_eval by this wave alone, or the
 // four-wave form (lm_eval_mw) where the workgroup has helper waves.
+// ---- tolerance mode of the LM refinement (EVH_SOLVER_FAST).  cv::solve(Ap, v, d, DECOMP_EIG) costs ~100 dependent Jacobi
+// rotations of ~1 400 cycles each; the same 8x8 symmetric positive definite system by LDL^T in one lane is ~3 000 cycles.
+// These systems are graded over ~14 orders of magnitude (raw pixel coordinates: smallest eigenvalue ~5 x the eigen-solve's
+// truncation threshold), so along the weakest direction the two solvers differ in the leading digits of the step and, LM being
+// cut after 10 iterations, H ends up to ~6e-4 px (corners) away from OpenCV's -- an opt-in mode (include/evhip.h); the RANSAC
+// draw, the inlier masks and the refit are untouched.  Returns false when a pivot is not positive (the
+// caller then takes the exact path), so nothing is ever solved with a factorisation that does not exist.
+__device__ bool ldl8_factor(const double* A /*LDS, symmetric 8x8*/, double (&Lm)[28], double (&Dinv)[8]) {
+  double Dd[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    double dj = A[j * 8 + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) { const double l = Lm[(j * (j - 1)) / 2 + k]; dj -= l * l * Dd[k]; }
+    if (!(dj > 0)) return false;
+    Dd[j] = dj;
+    Dinv[j] = 1.0 / dj;
+#pragma unroll
+    for (int i = j + 1; i < 8; i++) {
+      double t = A[i * 8 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= Lm[(i * (i - 1)) / 2 + k] * Lm[(j * (j - 1)) / 2 + k] * Dd[k];
+      Lm[(i * (i - 1)) / 2 + j] = t * Dinv[j];
+    }
+  }
+  return true;
+}
+__device__ void ldl8_solve(const double (&Lm)[28], const double (&Dinv)[8], const double (&b)[8], double (&x)[8]) {
+  double y[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double t = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t -= Lm[(i * (i - 1)) / 2 + k] * y[k];
+    y[i] = t;
+  }
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    double t = y[i] * Dinv[i];
+#pragma unroll
+    for (int k = i + 1; k < 8; k++) t -= Lm[(k * (k - 1)) / 2 + i] * x[k];
+    x[i] = t;
+  }
+}
+// lane 0: x = A^-1 b (b != null) or x[0] = max_i |(A^-1)_ii| (b == null); flag in ok (LDS int)
+__device__ void fast_solve8(int lane, const double* A, const double* b, double* x, int* ok) {
+  if (lane == 0) {
+    double Lm[28], Dinv[8];
+    bool good = ldl8_factor(A, Lm, Dinv);
+    if (good) {
+      if (b) {
+        double bb[8], xx[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) bb[i] = b[i];
+        ldl8_solve(Lm, Dinv, bb, xx);
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = xx[i];
+      } else {
+        double mv = 0;
+        for (int c = 0; c < 8; c++) {
+          double e[8], col[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) e[i] = i == c ? 1.0 : 0.0;
+          ldl8_solve(Lm, Dinv, e, col);
+          double dc = 0;
+#pragma unroll
+          for (int i = 0; i < 8; i++) dc = i == c ? col[i] : dc;
+          mv = fmax(mv, fabs(dc));
+        }
+        x[0] = mv;
+      }
+    }
+    *ok = good ? 1 : 0;
+  }
+}
+
 template <typename EvalJ, typename EvalN>
 __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const float* rows, int count,
                                          unsigned long long* prof, EvalJ evalJ, EvalN evalN /* residuals at S.xd -> sc[5], sc[6] */) {
@@ -1098,7 +1175,15 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
       S.Ap[lane] = i == j ? S.A8[lane] + S.sc[2] * S.D[i] : S.A8[lane];
     }
     WSYNC();
-    eig_solve8_wave(M, lane, S.Ap, S.v, S.d, prof);
+    bool solved = false;
+    if (S.fast) {
+      const unsigned long long pt0 = pf_now();
+      fast_solve8(lane, S.Ap, S.v, S.d, &S.ib[2]);
+      WSYNC();
+      solved = S.ib[2] != 0;
+      pf_add(prof, PF_SOLVE8, pf_now() - pt0);
+    }
+    if (!solved) eig_solve8_wave(M, lane, S.Ap, S.v, S.d, prof);
     if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
     WSYNC();
     pe = pf_now();
@@ -1136,7 +1221,15 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
     }
     WSYNC();
     if (S.ib[1]) {
-      eig_solve8_wave(M, lane, S.A8, nullptr, S.Inv, prof);
+      bool inverted = false;
+      if (S.fast) {
+        fast_solve8(lane, S.A8, nullptr, S.Inv, &S.ib[2]);      // S.Inv[0] = max |diag(A^-1)|
+        WSYNC();
+        inverted = S.ib[2] != 0;
+        if (inverted && lane == 0) { const double mv = S.Inv[0]; for (int i = 0; i < 8; i++) S.Inv[i * 8 + i] = mv; }
+        WSYNC();
+      }
+      if (!inverted) eig_solve8_wave(M, lane, S.A8, nullptr, S.Inv, prof);
       if (lane == 0) {
         double maxval = DBL_EPSILON;
         for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(S.Inv[i * 8 + i]));
@@ -1837,6 +1930,7 @@ __device__ __forceinline__ BlockLds<NW, LANES>& block_lds() {
 template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_find_homography(EvhRansacArgs A) {
   BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
+  if (threadIdx.x == 0) B.s.fast = A.fast_solver;   // read after the first barrier of the solve
   const int tid = threadIdx.x;
   const int n = A.n_fixed;
   const bool found = find_homography_block<NW, LANES>(B, A.pts, n, A.thr, A.max_iters, A.conf, A.force_max, A.mask, A.crow, A.info, A.prof, A.lane_v);
@@ -1860,6 +1954,7 @@ __global__ __launch_bounds__(NW * NL) void k_static_filter(const double* H, cons
 template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_ransac_static(EvhRansacArgs A) {
   BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
+  if (threadIdx.x == 0) B.s.fast = A.fast_solver;   // read after the first barrier of the solve
   const int p = blockIdx.x, tid = threadIdx.x;
   if (A.status[p] != EVH_PAIR_OK) { if (tid == 0) A.npts2[p] = 0; return; }
   const int n = A.npts[p];
@@ -1883,6 +1978,7 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_static(EvhRansacArgs A) {
 template <int NW, bool LANES>
 __global__ __launch_bounds__(NW * NL) void k_ransac_final_pairs(EvhRansacArgs A) {
   BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
+  if (threadIdx.x == 0) B.s.fast = A.fast_solver;   // read after the first barrier of the solve
   const int p = blockIdx.x, tid = threadIdx.x;
   int st = A.status[p];
   if (st == EVH_PAIR_OK) {
@@ -1935,6 +2031,7 @@ __global__ __launch_bounds__(NW * NL) void k_ransac_final_stream(EvhRansacArgs A
   // one workgroup per stream: block s scans the npairs pairs whose per-pair slots start at s * pitch (several streams
   // of one batch sit `pitch` pair slots apart); H / status are written compactly at s * npairs + p
   BlockLds<NW, LANES>& B = block_lds<NW, LANES>();
+  if (threadIdx.x == 0) B.s.fast = A.fast_solver;   // read after the first barrier of the solve
   const int tid = threadIdx.x, s = blockIdx.x;
   const double* Hsup0 = A.Hsup0 ? A.Hsup0 + 18 * s : nullptr;
   const double* Hprev0 = A.Hprev0 ? A.Hprev0 + 18 * s : nullptr;
@@ -2084,6 +2181,7 @@ __global__ __launch_bounds__(4 * NL) void k_scan_hyp(EvhRansacArgs A, int p, int
 // the serial part of pair p: replay of the hypotheses, refinement, step of the scan; grid = nstreams
 __global__ __launch_bounds__(4 * NL) void k_scan_finish(EvhRansacArgs A, int p, int npairs, int pitch, ScanWs W) {
   BlockLds<4, false>& B = block_lds<4, false>();
+  if (threadIdx.x == 0) B.s.fast = A.fast_solver;
   const int tid = threadIdx.x, s = blockIdx.x;
   ScanState& T = W.state[s];
   if (T.aborted) return;
@@ -2159,6 +2257,7 @@ __global__ __launch_bounds__(4 * NL) void k_static_hyp(EvhRansacArgs A, ScanWs W
 
 __global__ __launch_bounds__(4 * NL) void k_static_finish(EvhRansacArgs A, ScanWs W) {
   BlockLds<4, false>& B = block_lds<4, false>();
+  if (threadIdx.x == 0) B.s.fast = A.fast_solver;
   const int p = blockIdx.x, tid = threadIdx.x;
   if (A.status[p] != EVH_PAIR_OK) { if (tid == 0) A.npts2[p] = 0; return; }
   const int n = A.npts[p];

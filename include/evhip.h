@@ -137,6 +137,19 @@ int evh_set_fast_lift(evh_ctx* ctx, int on);
  * EVH_ORDER_CANONICAL: every tie at the cut kept, key points in (level, y, x) order (rounds 1-3); faster (lifting applies),
  *   H agrees with the reference only where RANSAC's consensus does not depend on the draw. */
 enum { EVH_ORDER_CANONICAL = 0, EVH_ORDER_OPENCV = 1 };
+/* The 8x8 linear systems of findHomography's Levenberg-Marquardt refinement (matching.py:156-157, utils.py:356-358 ->
+ * cv::findHomography -> LMSolver -> cv::solve(DECOMP_EIG)).
+ * EVH_SOLVER_EXACT (default): the operator's own Jacobi eigen-solve, rotation by rotation in its order -- H bit-identical to the
+ *   CPU restatement (and, where the consensus agrees, within 1e-7 of the reference's recorded run).
+ * EVH_SOLVER_FAST: LDL^T of the same systems (a non-positive pivot falls back to the exact path).  The random draw, the
+ *   inlier masks and the refit are unchanged and a stream pair costs ~45 % less (bench.py --config 3: 2.0 k -> 3.8 k pairs/s),
+ *   but H is no longer OpenCV's to the digit: the systems are graded over 14 orders of magnitude (raw pixel coordinates), the
+ *   loop is cut after 10 iterations, and where the data do not determine H the end points differ -- measured: frame corners
+ *   up to 6e-4 px, SURVEY 8d's floored-relative h_err up to 3.6e-3 (tests/test_gpu_parity.py::test_fast_solver_mode).
+ *   For callers who need the geometry, not the operator's digits. */
+enum { EVH_SOLVER_EXACT = 0, EVH_SOLVER_FAST = 1 };
+int evh_set_solver_mode(evh_ctx* ctx, int mode);
+int evh_get_solver_mode(const evh_ctx* ctx);
 /* largest max_features evh_create accepts (the matching filter keeps five lists of a frame slot's rows in LDS) */
 #define EVH_MAX_FEATURES 5984
 int evh_set_keypoint_order(evh_ctx* ctx, int mode);

@@ -1248,3 +1248,67 @@ def test_tie_heavy_frame_mid_stream_reruns_on_larger_slots():
                                 features_type_list=["ORB"])
         Hd = np.array([d[k]["H"] for k in range(2, len(frames) + 1)])
         assert np.allclose(Hd, Ho, rtol=1e-9, atol=1e-12), chunk
+
+
+def test_fast_solver_mode():
+    """EVH_SOLVER_FAST (include/evhip.h): LM's 8x8 systems by LDL^T instead of the operator's Jacobi eigen-solve.  The draw, the
+    masks and the refit are untouched, so statuses must be identical.  What can be asked of H, measured before the bars below
+    were written: findHomography refines on raw pixel coordinates, so J^T J is graded over 14 orders of magnitude (the
+    oracle's eigen-solves on this stream: smallest eigenvalue = 5 x the truncation threshold 2 eps trace); along its weakest
+    direction ANY two solvers differ in the leading digits of the step, LM is cut off after 10 iterations, and the end points
+    differ where the data do not determine H: corners up to 6e-4 px, the perspective row 4e-9 absolute, SURVEY 8d's
+    floored-relative h_err 3.6e-3 (exact mode: 1e-9).  So the fast mode is NOT inside the north-star's 1e-3 on every pair --
+    it is an opt-in for callers who care about the geometry (sub-milli-pixel) rather than about OpenCV's digits; the default
+    stays exact.  Bars: corners 5e-3 px, perspective row 1e-7, affine part 1e-2 floored-relative, h_err 2e-2."""
+    from evenvizion_amd._lib import Context, SOLVER_EXACT, SOLVER_FAST
+    seen = {"h_err": 0.0, "corner": 0.0, "abs": 0.0, "aff_rel": 0.0, "pairs": 0}
+
+    def check(Hg, Hw, status, w, h):
+        for p in range(len(status)):
+            if status[p] != 0:
+                continue
+            seen["pairs"] += 1
+            seen["h_err"] = max(seen["h_err"], h_err(Hg[p], Hw[p]))
+            seen["corner"] = max(seen["corner"], corner_err(Hg[p], Hw[p], w, h))
+            seen["abs"] = max(seen["abs"], float(np.abs(Hg[p][2, :2] - Hw[p][2, :2]).max()))
+            seen["aff_rel"] = max(seen["aff_rel"], float((np.abs(Hg[p][:2] - Hw[p][:2]) / np.maximum(np.abs(Hw[p][:2]), [[1e-3, 1e-3, 1.0]] * 2)).max()))
+
+    frames, _ = S.make_pair_batch(4, 6, 400, 224)
+    Ho, so = O.pairs_gray_batch(frames)
+    c = Context(device=0, max_w=400, max_h=224, max_features=500, max_frames=64)
+    try:
+        assert c.get_solver_mode() == SOLVER_EXACT
+        c.set_solver_mode(SOLVER_FAST)
+        H = torch.zeros(6, 9, dtype=torch.float64, device="cuda"); st = torch.full((6,), -1, dtype=torch.int32, device="cuda")
+        c.pair_homography_batch(dev(frames), 6, 0, H, st)
+        c.synchronize()
+        assert np.array_equal(st.cpu().numpy(), so)
+        check(H.cpu().numpy().reshape(-1, 3, 3), Ho, so, 400, 224)
+        pan = S.make_pan_stream(71, 61, 400, 224, step=6.0)
+        for force in (False, True):
+            Hs, ss, rc = O.stream_gray(pan, force_max_iters=force)
+            H = torch.zeros(60, 9, dtype=torch.float64, device="cuda"); st = torch.full((60,), -1, dtype=torch.int32, device="cuda")
+            c.stream_homography_batch(dev(pan), H, st, force_max_iters=force)
+            c.synchronize()
+            assert rc == -1 and np.array_equal(st.cpu().numpy(), ss), force
+            check(H.cpu().numpy().reshape(-1, 3, 3), Hs, ss, 400, 224)
+    finally:
+        c.close()
+    fr, _ = S.make_stream(12, 7, 1280, 720)
+    Hs, ss, rc = O.stream_gray(fr, nfeatures=2000)
+    c = Context(device=0, max_w=1280, max_h=720, max_features=2000, max_frames=8)
+    try:
+        c.set_solver_mode(SOLVER_FAST)
+        H = torch.zeros(6, 9, dtype=torch.float64, device="cuda"); st = torch.full((6,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch(dev(fr), H, st, nfeatures=2000)
+        c.synchronize()
+        assert np.array_equal(st.cpu().numpy(), ss)
+        check(H.cpu().numpy().reshape(-1, 3, 3), Hs, ss, 1280, 720)
+    finally:
+        c.close()
+    print("fast solver against the oracle over %(pairs)d pairs: h_err %(h_err).2e, corners %(corner).2e px, perspective row %(abs).2e "
+          "absolute, affine part %(aff_rel).2e relative" % seen)
+    assert seen["corner"] <= BAR_CORNER and seen["abs"] <= BAR_ABS and seen["aff_rel"] <= BAR_AFF and seen["h_err"] <= BAR_HERR, seen
+
+
+BAR_CORNER, BAR_ABS, BAR_AFF, BAR_HERR = 5e-3, 1e-7, 1e-2, 2e-2

@@ -1,6 +1,7 @@
 """Multi-type stream probe: one synthetic stream through evh_stream_homography_batch_types (the reference's default
 FrameProcessing list SURF, SIFT, ORB and its sub-lists), 32 pairs per call.
-usage: python tools/types_probe.py [WxH ...]   (default 400x224 = the reference's default resize_width)"""
+usage: python tools/types_probe.py [WxH ...]   (default 400x224 = the reference's default resize_width)
+EVH_PROBE_SOLVER=fast: LM's systems by LDL^T (evh_set_solver_mode)."""
 import os, sys, time, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
@@ -15,6 +16,7 @@ for wh in (sys.argv[1:] or ["400x224"]):
     d = torch.from_numpy(S.gray_to_bgr(frames)).cuda()
     ctx = Context(device=0, max_w=w, max_h=h, max_features=500, max_frames=nfr)
     ctx.sift_enable(6144 if w <= 400 else 65535); ctx.surf_enable(4096 if w <= 400 else 24576)
+    ctx.set_solver_mode(1 if os.environ.get("EVH_PROBE_SOLVER") == "fast" else 0)
     for feats in (["ORB"], ["SIFT"], ["SURF"], ["SURF", "SIFT", "ORB"]):
         H = torch.zeros(nfr - 1, 9, dtype=torch.float64, device='cuda'); st = torch.zeros(nfr - 1, dtype=torch.int32, device='cuda')
         ctx.stream_homography_batch_types(d, H, st, feats); ctx.synchronize()
