@@ -751,9 +751,80 @@ __device__ __forceinline__ uint32_t vert_pass4(uint32_t c, uint32_t rd, uint32_t
   return BITOP3(Dm, Bm, H, (A | B) & C);
 }
 
+// The segment test itself, byte-parallel: bit 7 of byte j = pixel j of the quad IS a corner at threshold T (nine contiguous
+// ring pixels all darker than centre - T or all brighter than centre + T), K4 = (T + 1) * 0x01010101.  p = the quad's centre row
+// in the staged tile (p[0], p[1], p[2] = the dwords of x-4.., x.., x+4..); ring byte k of the four pixels = one dword, taken
+// straight (dx = 0) or cut out of two neighbours with v_alignbyte.  Contiguity of 9 out of 16 (cyclic) with three-input ANDs:
+// A3[k] = M[k] & M[k+1] & M[k+2], A9[k] = A3[k] & A3[k+3] & A3[k+6], any = OR_k A9[k] -- 40 v_bitop3 per polarity.
+// Used where every corner at the base threshold is wanted (reference key-point order): the exact score is then computed for the
+// corners only (~10 % of the pixels of a textured frame) instead of for every pixel.
+__device__ __forceinline__ uint32_t corner16_pass4(const uint32_t* p, uint32_t K4) {
+  const uint32_t H = 0x80808080u, Lm = 0x7F7F7F7Fu;
+  const uint32_t c = p[1];
+  const uint32_t t = (c | H) - K4;
+  const uint32_t cl = BITOP3(t, c, Lm, A & (B | C));
+  const uint32_t u = (c & Lm) + K4;
+  const uint32_t ch = BITOP3(u, c, H, A | (B & C));
+  const uint32_t clH = cl | H, chL = ch & Lm;
+  uint32_t r[16];
+  {
+    const uint32_t* q = p + 3 * FR_DW;                       // row y + 3: ring 15, 0, 1
+    const uint32_t l = q[0], m = q[1], rr = q[2];
+    r[0] = m; r[1] = __builtin_amdgcn_alignbyte(rr, m, 1); r[15] = __builtin_amdgcn_alignbyte(m, l, 3);
+  }
+  {
+    const uint32_t* q = p + 2 * FR_DW;                       // row y + 2: ring 14, 2
+    r[2] = __builtin_amdgcn_alignbyte(q[2], q[1], 2); r[14] = __builtin_amdgcn_alignbyte(q[1], q[0], 2);
+  }
+  {
+    const uint32_t* q = p + FR_DW;                           // row y + 1: ring 13, 3
+    r[3] = __builtin_amdgcn_alignbyte(q[2], q[1], 3); r[13] = __builtin_amdgcn_alignbyte(q[1], q[0], 1);
+  }
+  r[4] = __builtin_amdgcn_alignbyte(p[2], c, 3); r[12] = __builtin_amdgcn_alignbyte(c, p[0], 1);   // row y: ring 12, 4
+  {
+    const uint32_t* q = p - FR_DW;                           // row y - 1: ring 11, 5
+    r[5] = __builtin_amdgcn_alignbyte(q[2], q[1], 3); r[11] = __builtin_amdgcn_alignbyte(q[1], q[0], 1);
+  }
+  {
+    const uint32_t* q = p - 2 * FR_DW;                       // row y - 2: ring 10, 6
+    r[6] = __builtin_amdgcn_alignbyte(q[2], q[1], 2); r[10] = __builtin_amdgcn_alignbyte(q[1], q[0], 2);
+  }
+  {
+    const uint32_t* q = p - 3 * FR_DW;                       // row y - 3: ring 9, 8, 7
+    const uint32_t l = q[0], m = q[1], rr = q[2];
+    r[8] = m; r[7] = __builtin_amdgcn_alignbyte(rr, m, 1); r[9] = __builtin_amdgcn_alignbyte(m, l, 3);
+  }
+  uint32_t D[16], Bq[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    D[k] = swar_ge(clH, cl, r[k], r[k] & Lm);                // centre - (T + 1) >= ring: darker
+    Bq[k] = swar_ge(r[k] | H, r[k], ch, chL);                // ring >= centre + (T + 1): brighter
+  }
+  uint32_t d3[16], b3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    d3[k] = BITOP3(D[k], D[(k + 1) & 15], D[(k + 2) & 15], A & B & C);
+    b3[k] = BITOP3(Bq[k], Bq[(k + 1) & 15], Bq[(k + 2) & 15], A & B & C);
+  }
+  uint32_t dany = 0, bany = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const uint32_t d9a = BITOP3(d3[k], d3[(k + 3) & 15], d3[(k + 6) & 15], A & B & C);
+    const uint32_t d9b = BITOP3(d3[k + 1], d3[(k + 4) & 15], d3[(k + 7) & 15], A & B & C);
+    dany = BITOP3(dany, d9a, d9b, A | B | C);
+    const uint32_t b9a = BITOP3(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15], A & B & C);
+    const uint32_t b9b = BITOP3(b3[k + 1], b3[(k + 4) & 15], b3[(k + 7) & 15], A & B & C);
+    bany = BITOP3(bany, b9a, b9b, A | B | C);
+  }
+  const uint32_t Dm = BITOP3(dany, c, t, A & (B | C));       // & (centre >= T + 1): centre - (T + 1) did not wrap
+  const uint32_t Bm = BITOP3(bany, c, u, A & ~(B & C));      // & (centre + T + 1 <= 255)
+  return BITOP3(Dm, Bm, H, (A | B) & C);
+}
+
 // lifted path: only scores >= T are produced.  Phase A: 4-point pre-test at T (any 9-arc holds two adjacent
 // compass points), four pixels per 32-bit operation; a quad with at least one passing pixel is queued
 // (quad index | pass bits << 16).  Phase B: exact score of the queued pixels, 4 lanes per queued quad.
+template <bool FULL16 = false>
 __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, int x0, int y0, int T) {
   const uint32_t K4 = (uint32_t)(T + 1) * 0x01010101u;
   // tiles whose whole score plane lies inside the testable range need no per-pixel range checks (wave-uniform)
@@ -847,9 +918,13 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
         }
         if (INTERIOR || (rowok && cmask)) {
           const uint32_t* p = S.raw + mad24((uint32_t)(sr + 3), FR_DW, (uint32_t)sq);    // centre row, dword of x = xq-4
-          const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
-          P[k] = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu, __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4) &
-                 cmask;
+          if constexpr (FULL16) {
+            P[k] = corner16_pass4(p, K4) & cmask;
+          } else {
+            const uint32_t Lc = p[0], Mc = p[1], Rc = p[2], Mu = p[1 - 3 * FR_DW], Md = p[1 + 3 * FR_DW];
+            P[k] = pretest_pass4(Mc, Md, __builtin_amdgcn_alignbyte(Rc, Mc, 3), Mu, __builtin_amdgcn_alignbyte(Mc, Lc, 1), K4) &
+                   cmask;
+          }
         }
       }
       sr += 7; sq += 18;                                        // +256 quads = +7 rows +18 quads
@@ -857,6 +932,60 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
     }
   };
   if (interior) quads(std::true_type{}); else quads(std::false_type{});
+  const uint8_t* rawb = reinterpret_cast<const uint8_t*>(S.raw);
+  uint8_t* scoreb = reinterpret_cast<uint8_t*>(S.score);
+  // exact score of the pixel `j` of quad `qi`; writes the score byte when it reaches T
+  auto score_pixel = [&](int qi, int j, bool list) {
+    const int sr2 = qi / FS_DW, sq2 = qi - sr2 * FS_DW;
+    const int pos = sr2 * FQ_PITCH + sq2 * 4 + j;
+    const uint8_t* p = rawb + (sr2 + 3) * (FR_DW * 4) + sq2 * 4 + j + 4;
+    const int W = FR_DW * 4;
+    const int v = p[0];
+    i16 d[16];
+    d[0] = (i16)(v - p[3 * W]);       d[1] = (i16)(v - p[3 * W + 1]);   d[2] = (i16)(v - p[2 * W + 2]);
+    d[3] = (i16)(v - p[W + 3]);       d[4] = (i16)(v - p[3]);           d[5] = (i16)(v - p[-W + 3]);
+    d[6] = (i16)(v - p[-2 * W + 2]);  d[7] = (i16)(v - p[-3 * W + 1]);  d[8] = (i16)(v - p[-3 * W]);
+    d[9] = (i16)(v - p[-3 * W - 1]);  d[10] = (i16)(v - p[-2 * W - 2]); d[11] = (i16)(v - p[-W - 3]);
+    d[12] = (i16)(v - p[-3]);         d[13] = (i16)(v - p[W - 3]);      d[14] = (i16)(v - p[2 * W - 2]);
+    d[15] = (i16)(v - p[3 * W - 1]);
+    const int sc = fast_score_from_d(d);
+    if (sc >= T) {
+      scoreb[pos] = (uint8_t)sc;
+      if (list) {
+        const int k = atomicAdd(&S.scnt, 1);
+        if (k < FSC_CAP) S.scored[k] = (uint16_t)pos;
+      }
+    }
+  };
+  if constexpr (FULL16) {
+    // every passing pixel IS a corner (a fifth of the pixels of a textured frame): one lane per corner.  Queue of 16-bit
+    // entries quad << 2 | pixel in the words of S.lst (2048 entries); a tile with more corners than that is scored densely.
+    uint16_t* pq = reinterpret_cast<uint16_t*>(S.lst);
+    constexpr int PQ_CAP = 2 * (FS_H * FS_DW);
+    const int mine = __popc(P[0] & 0x80808080u) + __popc(P[1] & 0x80808080u) + __popc(P[2] & 0x80808080u) + __popc(P[3] & 0x80808080u);
+    int at = mine ? atomicAdd(&S.qcnt, mine) : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t m = P[k] & 0x80808080u;
+      while (m) {
+        const int b = __ffs(m) - 1;                  // bit 7, 15, 23 or 31
+        m &= m - 1;
+        if (at < PQ_CAP) pq[at] = (uint16_t)(((threadIdx.x + 256 * k) << 2) | (b >> 3));
+        at++;
+      }
+    }
+    __syncthreads();
+    const int np = S.qcnt;
+    if (np > PQ_CAP) {                               // workgroup-uniform
+      fast_dense_scores(S, L, x0, y0);
+      return;
+    }
+    for (int e = threadIdx.x; e < np; e += 256) {
+      const int ent = pq[e];
+      score_pixel(ent >> 2, ent & 3, false);
+    }
+    return;
+  }
   {
     const unsigned long long m0 = __ballot(P[0] != 0), m1 = __ballot(P[1] != 0), m2 = __ballot(P[2] != 0),
                              m3 = __ballot(P[3] != 0);
@@ -877,33 +1006,14 @@ __device__ __forceinline__ void fast_lift_scores(FastLds& S, const EvhLevel& L, 
 #endif
   __syncthreads();
   const int nq = S.qcnt;
-  const uint8_t* rawb = reinterpret_cast<const uint8_t*>(S.raw);
-  uint8_t* scoreb = reinterpret_cast<uint8_t*>(S.score);
-  // four lanes per queued quad.  (A pixel-granular list -- fewer busy waves -- was measured at +1.0 ms: the four
-  // lanes of a quad read neighbouring bytes of the same LDS words, scattered pixels conflict on the banks.)
+  // four lanes per queued quad.  (A pixel-granular list -- fewer busy waves -- was measured at +1.0 ms when a few dozen pixels
+  // per tile pass: the four lanes of a quad read neighbouring bytes of the same LDS words, scattered pixels conflict on the
+  // banks.  With the full segment test a fifth of the pixels pass and the pixel list wins: see FULL16 above.)
   for (int e = threadIdx.x; e < nq * 4; e += 256) {
     const uint32_t ent = S.lst[e >> 2];
     const int j = e & 3;
     if (!((ent >> (16 + 8 * (j & 1) + (j >> 1))) & 1u)) continue;
-    const int qi = (int)(ent & 0xFFFu);
-    const int sr2 = qi / FS_DW, sq2 = qi - sr2 * FS_DW;
-    const int pos = sr2 * FQ_PITCH + sq2 * 4 + j;
-    const uint8_t* p = rawb + (sr2 + 3) * (FR_DW * 4) + sq2 * 4 + j + 4;
-    const int W = FR_DW * 4;
-    const int v = p[0];
-    i16 d[16];
-    d[0] = (i16)(v - p[3 * W]);       d[1] = (i16)(v - p[3 * W + 1]);   d[2] = (i16)(v - p[2 * W + 2]);
-    d[3] = (i16)(v - p[W + 3]);       d[4] = (i16)(v - p[3]);           d[5] = (i16)(v - p[-W + 3]);
-    d[6] = (i16)(v - p[-2 * W + 2]);  d[7] = (i16)(v - p[-3 * W + 1]);  d[8] = (i16)(v - p[-3 * W]);
-    d[9] = (i16)(v - p[-3 * W - 1]);  d[10] = (i16)(v - p[-2 * W - 2]); d[11] = (i16)(v - p[-W - 3]);
-    d[12] = (i16)(v - p[-3]);         d[13] = (i16)(v - p[W - 3]);      d[14] = (i16)(v - p[2 * W - 2]);
-    d[15] = (i16)(v - p[3 * W - 1]);
-    const int s = fast_score_from_d(d);
-    if (s >= T) {
-      scoreb[pos] = (uint8_t)s;
-      const int k = atomicAdd(&S.scnt, 1);
-      if (k < FSC_CAP) S.scored[k] = (uint16_t)pos;
-    }
+    score_pixel((int)(ent & 0xFFFu), j, true);
   }
 }
 
@@ -1203,7 +1313,16 @@ __global__ __launch_bounds__(256, 8) void k_fast_main(FastArgs A) {
   const int T = A.lift_base ? EVH_FAST_THR : A.thr[f * EVH_NLEVELS + l];
   fast_stage(S, A.pyr + (int64_t)f * A.pyr_frame_bytes + L.off, L, x0, y0);
   __syncthreads();
-  if (T > EVH_FAST_THR || A.lift_base) {
+  if (A.lift_base) {
+    // reference key-point order: every corner at the base threshold, found by the full segment test, scored exactly, handed
+    // over as a row-major burst (fast_nms_collect_ordered walks the score plane, which is complete: zero where no corner is)
+    fast_lift_scores<true>(S, L, x0, y0, EVH_FAST_THR);
+    __syncthreads();
+    fast_nms_collect_ordered(S, L, x0, y0);
+    fast_emit_ordered(S, A, L, f, l, (int)blockIdx.x);
+    return;
+  }
+  if (T > EVH_FAST_THR) {
     fast_lift_scores(S, L, x0, y0, T);
     __syncthreads();
     if (S.scnt <= FSC_CAP) {                      // workgroup-uniform.  What is left is a few dozen scored pixels:
@@ -2209,8 +2328,15 @@ int evh_launch_fast(evh_ctx* c, int nframes, int share_group) {
   A.total_tiles = c->g.total_tiles;
   // the reference's key-point order is a function of EVERY corner at threshold 20 (k_select_cv): the threshold cannot be
   // lifted there, but the exact score is still only needed where the 4-point pre-test at 20 passes
-  // (measured and dropped: the lifted machinery at the base threshold, k_fast_main with lift_base = 1 -- 22.8 ms against
-  // 19.8 ms for the dense kernel on the 720p texture of SURVEY 8d, where the 4-point pre-test at 20 passes most quads)
+  // reference order + lifting allowed: the full 16-point segment test decides which pixels get an exact score (k_fast_main with
+  // lift_base; the 4-point pre-test alone was measured and dropped here: 22.8 ms against 19.8 ms dense on the 720p texture of
+  // SURVEY 8d, where it passes most quads).  EVH_FAST_DENSE=1 or evh_set_fast_lift(0): the dense kernel.
+  if (c->order_mode == EVH_ORDER_OPENCV && c->fast_lift && !getenv("EVH_FAST_DENSE")) {
+    A.lift_base = 1;
+    hipLaunchKernelGGL(k_fast_main, grid, dim3(256), 0, c->stream, A);
+    EVH_HIP(c, hipGetLastError());
+    return EVH_SUCCESS;
+  }
   if (!c->fast_lift || nsamp == 0 || c->order_mode == EVH_ORDER_OPENCV) {
     hipLaunchKernelGGL(k_fast, grid, dim3(256), 0, c->stream, A);
     EVH_HIP(c, hipGetLastError());
