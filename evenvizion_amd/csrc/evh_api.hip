@@ -465,6 +465,7 @@ int evh_create(int device, int max_w, int max_h, int max_features, int max_frame
     c->cv_mask_frame_words = mw + 64;
   }
   A_(dalloc(c, &c->d_cv_seq, F * (size_t)gmax.cand_frame_entries));
+  A_(dalloc(c, &c->d_cv_seq32, F * (size_t)gmax.cand_frame_entries));
   A_(dalloc(c, &c->d_cv_lpos, F * (size_t)gmax.cand_frame_entries));
   A_(dalloc(c, &c->d_cv_rpos, F * (size_t)gmax.cand_frame_entries));
   A_(dalloc(c, &c->d_cv_mask, F * 2 * (size_t)c->cv_mask_frame_words));
@@ -500,7 +501,7 @@ void evh_destroy(evh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_pyr, c->d_cand, c->d_cand_count, c->d_tabs, c->d_kp_xy, c->d_kp_meta, c->d_kp_resp, c->d_kp_angle,
-                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_cv_seq, c->d_cv_lpos, c->d_cv_rpos, c->d_cv_mask, c->d_cv_tdesc, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
+                  c->d_desc, c->d_kp_count, c->d_frame_flags, c->d_tmp_meta, c->d_tmp_resp, c->d_lvl_count, c->d_fast_thr, c->d_fast_hist, c->d_fast_redo, c->d_cv_seq, c->d_cv_seq32, c->d_cv_lpos, c->d_cv_rpos, c->d_cv_mask, c->d_cv_tdesc, c->d_area_tab, c->d_lane_v, c->d_fast_hint, c->d_knn_idx, c->d_knn_d2, c->d_pts, c->d_pts2, c->d_crow,
                   c->d_npts, c->d_npts2, c->d_pstatus, c->d_H1, c->d_mask, c->d_lm, c->d_info, c->d_small, c->d_scratch, c->d_scan_ws, c->d_filter_ws, c->d_merge_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   evh_sift_free(c);

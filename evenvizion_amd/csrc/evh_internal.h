@@ -102,6 +102,7 @@ struct evh_ctx {
   int order_mode = 1;             // EVH_ORDER_OPENCV
   int solver_mode = 0;            // EVH_SOLVER_EXACT
   unsigned long long* d_cv_seq = nullptr;   // [max_frames][cand_frame_entries] key << 32 | candidate, row-major then permuted
+  uint32_t* d_cv_seq32 = nullptr; // [max_frames][cand_frame_entries] the first retainBest works on the candidates themselves
   uint32_t* d_cv_lpos = nullptr;  // [max_frames][cand_frame_entries] stopper positions of the partition passes
   uint32_t* d_cv_rpos = nullptr;
   uint32_t* d_cv_mask = nullptr;  // [max_frames][2][cv_mask_frame_words] prefix table of the tiles' row counts
