@@ -408,6 +408,38 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "algorithmic_bytes_per_launch": int(by), "avg_launch_ms": round(stage_ms[dom], 4),
                 "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
+    # A stream config's dominant kernel is the sequential scan (one wave per SIMD, ~80 bytes per pair): an HBM fraction says
+    # nothing about it.  What bounds it is a chain of dependent f64 operations; the kernel can account its own cycles by phase
+    # (EVH_RANSAC_PROF), so one more step of the same workload is run in a child process with the accounting on and its
+    # per-pair cycle model is attached as roofline.scan_cycles (clock 2.4 GHz: cycles / 2.4e6 = ms per pair).
+    if dom == "ransac_final" and args.kind != "pairs" and rank == 0 and not args.skip_no_temporal and not os.environ.get("EVH_RANSAC_PROF"):
+        try:
+            import re
+            env = dict(os.environ, EVH_RANSAC_PROF="1")
+            for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "EVH_BENCH_FORCE_DIST"):
+                env.pop(k_, None)
+            argv = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                    "--cpu-pairs", "0", "--skip-no-temporal", "--gen-procs", "1", "--solver", args.solver, "--order", args.order]
+            if args.force_max_iters:
+                argv.append("--force-max-iters")
+            pr = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=600)
+            lines = [l for l in pr.stderr.splitlines() if l.startswith("[evh ransac_final prof]")]
+            if lines:
+                t = lines[-1]
+                def num(pat):
+                    m = re.search(pat, t)
+                    return float(m.group(1)) if m else None
+                roofline["scan_cycles"] = {
+                    "per_pair_total": num(r"total (\d+)"), "hypotheses": num(r"hyp (\d+)"), "compact": num(r"compact (\d+)"),
+                    "refit": num(r"refit (\d+)"), "lm": num(r" lm (\d+)"), "lm_iterations": num(r"iters ([\d.]+)"),
+                    "lm_solves": num(r"solve8 (\d+)"), "lm_evaluations": num(r"eval (\d+)"),
+                    "jacobi_rotations_9x9": num(r"9x9 ([\d.]+)"), "jacobi_rotations_8x8": num(r"8x8 ([\d.]+)"),
+                    "source": "EVH_RANSAC_PROF=1 on one more step of this workload in a child process (in-kernel s_memtime accounting, thread 0 of each scan)"}
+                tot = roofline["scan_cycles"]["per_pair_total"]
+                if tot:
+                    roofline["scan_cycles"]["ms_per_pair_at_2.4GHz"] = round(tot / 2.4e6, 4)
+        except Exception as e:      # the model is informational
+            roofline["scan_cycles"] = {"error": str(e)[:200]}
     # HBM bytes (PMC) and VALU instruction counts are NOT measured in this run: they come from the committed rocprofv3
     # --pmc passes of exactly this workload (profiles/traffic.json, profiles/valu.json, keyed by kernel group and
     # geometry) and are labelled as replayed; a workload without a committed pass reports null.
