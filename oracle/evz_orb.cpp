@@ -6,7 +6,7 @@
  *   evenvizion/processing/frame_processing.py:59-61   cv2.ORB_create().detectAndCompute(frame, None)
  * The arithmetic lives in opencv-contrib-python==3.4.2.17 (requirements.txt:3), which is not part of
  * /root/reference; what follows restates the published OpenCV 3.4 algorithm (imgproc resize/color/smooth,
- * features2d fast/orb).  No reference test pins these operators: parity unpinned (see evz_oracle.h).
+ * features2d fast/orb).  No reference TEST pins these operators one by one; they are pinned jointly, since round 4, by the reference's own video and recorded result (tests/test_capture_golden.py: 109 of 120 pairs of dict_with_homography_matrix.json within 1e-3) -- see evz_oracle.h.
  *
  * Compile with -ffp-contract=off: float expressions below are evaluated one IEEE operation at a time.
  */

@@ -10,9 +10,11 @@
  * filter with the plain row form and the symmetric column form, hal::exp32f / fastAtan2 / magnitude32f,
  * Matx33f::solve by Cramer's rule, KeyPointsFilter::removeDuplicatedSorted).
  *
- * PARITY STATUS: RESTATED FROM RECALL, PARITY UNPINNED.  opencv-contrib-python==3.4.2.17 (requirements.txt:3) is
+ * PARITY STATUS: restated from recall; pinned jointly, since round 4, by the reference's own video and recorded result (tests/test_capture_golden.py: 109 of 120 pairs of dict_with_homography_matrix.json within 1e-3).  The agreeing pairs still differ by 1e-5 .. 1e-3: the scale space here is the
+ * operator's own float filter in scalar form, while an IPP-enabled wheel may route GaussianBlur(CV_32F) through ippiFilterGaussian,
+ * whose arithmetic is not published -- sub-pixel key-point coordinates then differ in their last digits.  opencv-contrib-python==3.4.2.17 (requirements.txt:3) is
  * a third-party wheel absent from /root/reference and from this image; the reference holds no vector at this
- * boundary (its one golden JSON was produced from a video that cannot be decoded here).  Where the wheel's build
+ * boundary alone.  Where the wheel's build
  * (SSE2 / AVX2 / FMA3 / IPP dispatch) decides the last bit -- FMA in the filter rows, 8-lane partial sums of the
  * descriptor norm, the vector or scalar body of exp32f -- this file takes the plain scalar, non-fused form, and for
  * exp32f the float-polynomial form of its vector body; powf / cosf / sinf are replaced by deterministic double

@@ -286,7 +286,7 @@ def stream_gray(frames, nfeatures=500, force_max_iters=False):
     return H.reshape(-1, 3, 3), st, rc
 
 
-# ---- N4: SIFT (oracle/evz_sift.cpp; restated from recall, parity unpinned) -------------------------------------------
+# ---- N4: SIFT (oracle/evz_sift.cpp; restated from recall; pinned jointly by tests/test_capture_golden.py) -------------------------------------------
 def sift_layout(w, h):
     ow = np.zeros(16, np.int32); oh = np.zeros(16, np.int32)
     n = lib().evo_sift_layout(int(w), int(h), _p(ow), _p(oh), 16)
@@ -379,7 +379,7 @@ def stream_gray_types(frames, features, nfeatures=500, force_max_iters=False, Hs
     return H.reshape(-1, 3, 3), st, rc
 
 
-# ---- N4: SURF (oracle/evz_surf.cpp; restated from recall, parity unpinned) -------------------------------------------
+# ---- N4: SURF (oracle/evz_surf.cpp; restated from recall; pinned jointly by tests/test_capture_golden.py) -------------------------------------------
 def integral(gray):
     gray = _u8(gray)
     h, w = gray.shape
