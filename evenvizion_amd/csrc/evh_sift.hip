@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void k_sift_upsample(const uint8_t* __restrict
   dst[(int64_t)f * dst_frame_floats + (int64_t)dy * dstride + dx] = d0 * b0 + d1 * b1;
 }
 
-// ---- GaussianBlur on float: row pass  s = k0*S0; s += kj*Sj  (left to right) --------------------------------------
+// ---- GaussianBlur on float: row pass  s = k0*S0; s = fma(kj, Sj, s)  (left to right) --------------------------------------
+// The reference's OpenCV build runs its 8-lane FMA row body over columns [0, w & ~7) and the plain scalar loop (multiply, then
+// add) over the rest; the column pass likewise fuses [0, w & ~15) only.  The reference's recorded run is reproduced to the last
+// bit with exactly this split (oracle/evz_sift.cpp gaussian_blur, tests/test_capture_golden.py), so it is part of the result.
 __global__ __launch_bounds__(256) void k_sift_blur_row(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst,
                                                        int64_t dst_frame, int w, int h, int stride, SiftTaps T) {
   __shared__ float L[256 + SMAXTAPS];
@@ -100,11 +103,15 @@ __global__ __launch_bounds__(256) void k_sift_blur_row(const float* __restrict__
   const int x = x0 + threadIdx.x;
   if (x >= w) return;
   float s = T.k[0] * L[threadIdx.x];
-  for (int j = 1; j < T.n; j++) s += T.k[j] * L[threadIdx.x + j];
+  if (x < (w & ~7)) {
+    for (int j = 1; j < T.n; j++) s = fmaf(T.k[j], L[threadIdx.x + j], s);
+  } else {
+    for (int j = 1; j < T.n; j++) s = __fadd_rn(s, __fmul_rn(T.k[j], L[threadIdx.x + j]));
+  }
   dst[(int64_t)f * dst_frame + (int64_t)y * stride + x] = s;
 }
 
-// ---- column pass, the symmetric form  s = k_mid*S0; s += k_j*(S[+j] + S[-j]) ---------------------------------------
+// ---- column pass, the symmetric form  s = k_mid*S0; s = fma(k_j, S[+j] + S[-j], s) ---------------------------------------
 #define SC_W 64
 #define SC_H 32
 __global__ __launch_bounds__(256) void k_sift_blur_col(const float* __restrict__ src, int64_t src_frame, float* __restrict__ dst,
@@ -123,7 +130,11 @@ __global__ __launch_bounds__(256) void k_sift_blur_col(const float* __restrict__
     if (y >= h) break;
     const float* c = L + (yy + r) * SC_W + tx;
     float s = T.k[r] * c[0];
-    for (int j = 1; j <= r; j++) s += T.k[r + j] * (c[j * SC_W] + c[-j * SC_W]);
+    if (x < (w & ~15)) {
+      for (int j = 1; j <= r; j++) s = fmaf(T.k[r + j], c[j * SC_W] + c[-j * SC_W], s);
+    } else {
+      for (int j = 1; j <= r; j++) s = __fadd_rn(s, __fmul_rn(T.k[r + j], c[j * SC_W] + c[-j * SC_W]));
+    }
     dst[(int64_t)f * dst_frame + (int64_t)y * stride + x] = s;
   }
 }

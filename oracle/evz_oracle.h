@@ -58,6 +58,10 @@ void evo_fast_score_map(const uint8_t* img, int w, int h, int threshold, uint8_t
 void evo_set_orb_order(int mode);
 int evo_get_orb_order(void);
 long evo_orb_depth_limit_hits(void);   /* nth_element calls so far that fell back to heap select (introselect depth limit) */
+/* which multiply-adds of SIFT's float Gaussian filter are fused: 2 = the vector bodies only (default, pinned by the reference's
+ * golden: all 120 recorded pairs reproduced exactly), 0 = none, 1 = every column (evz_sift.cpp gaussian_blur) */
+void evo_set_sift_blur_mode(int mode);
+int evo_get_sift_blur_mode(void);
 int evo_orb_level_candidates(const uint8_t* img, int w, int h, int quota, int* xs, int* ys, int* scores, int cap);
 /* 7x7/sigma=2 8-bit Gaussian blur with reflect-101 borders (K6 first half) */
 void evo_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst);

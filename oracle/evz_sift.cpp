@@ -118,12 +118,19 @@ void gauss_kernel(double sigma, std::vector<float>& k) {
   for (int i = 0; i < n; i++) k[i] = (float)(k[i] * sum);
 }
 
-/* GaussianBlur(src, dst, Size(), sigma, sigma), float, BORDER_REFLECT_101: row filter s = k0*S0; s += kj*Sj (left to
- * right), column filter s = k_mid*S0; s += k_j*(S[+j] + S[-j]) (the symmetric form) */
+/* GaussianBlur(src, dst, Size(), sigma, sigma), float, BORDER_REFLECT_101: row filter s = k0*S0; s (+)= kj*Sj (left to right),
+ * column filter s = k_mid*S0; s (+)= k_j*(S[+j] + S[-j]) (the symmetric form).  Which multiply-adds are FUSED is decided by the
+ * reference's recorded run (tests/test_capture_golden.py, tools/golden_compare.py): the wheel's AVX2 + FMA3 dispatch of the float
+ * filters fuses the 8-lane row body, columns [0, w & ~7), and the 16-column body of the column filter, columns [0, w & ~15);
+ * the remaining columns go through the 4-lane / scalar remainders, whose products are rounded before the add.  With exactly
+ * this split all 120 recorded pairs are reproduced to the last printed digit.  For the record: no fusion anywhere, 109 of 120
+ * within 1e-3 and none exact; fusion everywhere, 120 within 1e-3 and 71 exact; double accumulation, 98 within 1e-3. */
+int g_blur_mode = 2;   /* 2: the split above (pinned); 0: no fusion; 1: fusion in every column -- evo_set_sift_blur_mode, for the record */
 void gaussian_blur(const Img& src, Img& dst, double sigma) {
   std::vector<float> k;
   gauss_kernel(sigma, k);
   const int n = (int)k.size(), r = n / 2, w = src.w, h = src.h;
+  const int wrow = g_blur_mode == 2 ? (w & ~7) : g_blur_mode == 1 ? w : 0, wcol = g_blur_mode == 2 ? (w & ~15) : g_blur_mode == 1 ? w : 0;
   Img tmp; tmp.create(w, h);
   std::vector<int> xi(w + 2 * r);
   for (int i = 0; i < w + 2 * r; i++) xi[i] = reflect101(i - r, w);
@@ -131,7 +138,8 @@ void gaussian_blur(const Img& src, Img& dst, double sigma) {
     const float* S = &src.d[(size_t)y * w];
     for (int x = 0; x < w; x++) {
       float s = k[0] * S[xi[x]];
-      for (int j = 1; j < n; j++) s += k[j] * S[xi[x + j]];
+      if (x < wrow) { for (int j = 1; j < n; j++) s = fmaf(k[j], S[xi[x + j]], s); }         /* the 8-lane FMA body */
+      else { for (int j = 1; j < n; j++) s = s + k[j] * S[xi[x + j]]; }                        /* the scalar remainder */
       tmp.at(y, x) = s;
     }
   }
@@ -139,7 +147,11 @@ void gaussian_blur(const Img& src, Img& dst, double sigma) {
   for (int y = 0; y < h; y++) {
     for (int x = 0; x < w; x++) {
       float s = k[r] * tmp.at(y, x);
-      for (int j = 1; j <= r; j++) s += k[r + j] * (tmp.at(reflect101(y + j, h), x) + tmp.at(reflect101(y - j, h), x));
+      if (x < wcol) {                                                                     /* the 16-column FMA body */
+        for (int j = 1; j <= r; j++) s = fmaf(k[r + j], tmp.at(reflect101(y + j, h), x) + tmp.at(reflect101(y - j, h), x), s);
+      } else {                                                                                 /* 4-lane and scalar remainders */
+        for (int j = 1; j <= r; j++) s = s + k[r + j] * (tmp.at(reflect101(y + j, h), x) + tmp.at(reflect101(y - j, h), x));
+      }
       out.at(y, x) = s;
     }
   }
@@ -516,6 +528,8 @@ extern "C" int evo_sift_detect(const uint8_t* gray, int w, int h, float* xy, uin
 }
 
 extern "C" float evo_sift_exp32f(float x) { return exp32f(x); }
+extern "C" void evo_set_sift_blur_mode(int mode) { g_blur_mode = (mode >= 0 && mode <= 2) ? mode : 2; }
+extern "C" int evo_get_sift_blur_mode(void) { return g_blur_mode; }
 extern "C" float evo_sift_exp2(float x) { return det_exp2(x); }
 
 /* BruteForce (NORM_L2) 2-NN on float descriptors, matching.py:102-108 on float32[N,dim]: hal::normL2Sqr_ (two 4-lane

@@ -46,6 +46,15 @@ def get_orb_order():
     return int(lib().evo_get_orb_order())
 
 
+def set_sift_blur_mode(mode):
+    """2 (default, pinned): SIFT's Gaussian filter fuses its multiply-adds in the vector bodies only; 0: nowhere; 1: everywhere."""
+    lib().evo_set_sift_blur_mode(int(mode))
+
+
+def get_sift_blur_mode():
+    return int(lib().evo_get_sift_blur_mode())
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -113,9 +113,9 @@ def test_other_sizes_and_budgets(w, h, nfeat):
 
 def test_reference_video_end_to_end(video_gray, tmp_path, monkeypatch):
     """evenvizion_component.py's path on its own test video: libevcap frames -> get_homography_dict (SURF + SIFT + ORB at 400,
-    the reference's defaults) on the device == the oracle's stream on the same frames; and the first pairs, before one
-    diverging RANSAC consensus (pair 3, see tests/test_capture_golden.py) moves the running plane, equal the JSON the
-    reference's authors committed."""
+    the reference's defaults) on the device == the oracle's stream on the same frames == (all 120 pairs, see
+    tests/test_capture_golden.py) the JSON the reference's authors committed for it: the drop-in claim, checked on the
+    reference's own input against the reference's own output.  Bound: the north star's 1e-3; measured: 0 (every matrix equal to the last digit)."""
     from evenvizion_amd.processing import get_homography_dict
     frames, gray = video_gray
     d = get_homography_dict(capture.VideoCapture(MP4), resize_width=400)
@@ -127,8 +127,12 @@ def test_reference_video_end_to_end(video_gray, tmp_path, monkeypatch):
     gold = json.load(open(GOLD))
     G = np.array([gold[str(k)]["H"] for k in range(2, 122)])
     tau = np.array([[1e-3, 1e-3, 1.0], [1e-3, 1e-3, 1.0], [1e-6, 1e-6, 1.0]])
-    rel = [(np.abs(Hg[k] - G[k]) / np.maximum(np.abs(G[k]), tau)).max() for k in range(3)]
-    assert max(rel) <= 1e-3, rel
+    rel = np.array([(np.abs(Hg[k] - G[k]) / np.maximum(np.abs(G[k]), tau)).max() for k in range(120)])
+    print("device vs the reference's recorded run: max rel %.2e, pairs equal to the last digit %d of 120"
+          % (rel.max(), (np.abs(Hg - G).reshape(120, -1).max(1) == 0).sum()))
+    assert rel.max() <= 1e-3, np.nonzero(rel > 1e-3)[0].tolist()
+    assert rel.max() <= 1e-6, rel.max()          # what is actually seen: 0.0 -- all 120 device matrices equal the recorded ones
+    assert (np.abs(Hg - G).reshape(120, -1).max(1) == 0).sum() >= 100
     # the CLI writes the same dictionary
     from evenvizion_amd import component
     monkeypatch.chdir(tmp_path)
