@@ -12,7 +12,7 @@
  *   evenvizion/processing/utils.py:118-145      matrix_superposition
  *   evenvizion/processing/video_processing.py:58-107  the stream loop
  * findHomography's arithmetic (calib3d ptsetreg/fundam/levmarq, core Jacobi) is restated from the published
- * OpenCV 3.4 algorithm; pinned jointly with the other operators, since round 4, by the reference's own video and recorded result (tests/test_capture_golden.py: 109 of 120 pairs of dict_with_homography_matrix.json within 1e-3) -- see evz_oracle.h.  The Python-glue functions are pinned by the
+ * OpenCV 3.4 algorithm; pinned jointly with the other operators, since round 4, by the reference's own video and recorded result (tests/test_capture_golden.py: all 120 matrices of dict_with_homography_matrix.json reproduced to the last digit) -- see evz_oracle.h.  The Python-glue functions are pinned by the
  * fixtures in tests/golden/ captured from the reference.
  *
  * Compile with -ffp-contract=off.

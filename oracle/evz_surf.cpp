@@ -11,7 +11,7 @@
  * a rotated (21 s) x (21 s) window resized to 21 x 21 with INTER_AREA, 4 x 4 x 8 sums of Gaussian-weighted gradients,
  * unit length.
  *
- * PARITY STATUS: restated from recall; pinned jointly, since round 4, by the reference's own video and recorded result (tests/test_capture_golden.py: 109 of 120 pairs of dict_with_homography_matrix.json within 1e-3) (opencv-contrib-python==3.4.2.17, requirements.txt:3, is absent
+ * PARITY STATUS: restated from recall; pinned jointly, since round 4, by the reference's own video and recorded result (tests/test_capture_golden.py: all 120 matrices of dict_with_homography_matrix.json reproduced to the last digit) (opencv-contrib-python==3.4.2.17, requirements.txt:3, is absent
  * from /root/reference and from this image; the reference holds no vector at this boundary).  sin / cos of the dominant
  * direction go through the oracle's deterministic evo_sincos (double, rounded to float) instead of libm's sinf / cosf so
  * that the HIP build can reproduce every bit.
