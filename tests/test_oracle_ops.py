@@ -1,6 +1,7 @@
 """Independent checks of the oracle's restated operators (parity with OpenCV itself is unpinned -- no cv2 in the
 image and no vectors in the reference; these tests pin the oracle against definitions, numpy and analytic truth)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -324,3 +325,16 @@ def test_pyramid_resize_against_scipy():
         assert want.shape == (lh, lw)
         diff = pyr[l].astype(np.float64) - want
         assert np.abs(diff).max() <= 1.0 and abs(diff.mean()) < 0.05, (l, np.abs(diff).max(), diff.mean())
+
+
+def test_introselect_statement_equals_libstdcxx(tmp_path):
+    """The oracle's statement of libstdc++'s introselect (what fixes the ORDER retainBest leaves ORB's key points in) against
+    the real std::nth_element of this image's libstdc++: 20 300 sequences with few distinct keys, every permutation equal.
+    (At the depth limit the oracle calls std::nth_element itself; the device's heap-select is checked against that in
+    tests/test_gpu_order.py.)"""
+    import subprocess
+    exe = str(tmp_path / "nth_check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "nth_check.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, src])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("mismatches 0 of "), r.stdout + r.stderr
