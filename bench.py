@@ -447,7 +447,7 @@ def main():
     for fname, field in (("traffic.json", "traffic"), ("valu.json", "valu_issue")):
         path = os.path.join(ROOT, "profiles", fname)
         try:
-            entry = json.load(open(path)).get(key) if (args.kind == "pairs" and os.path.exists(path)) else None
+            entry = json.load(open(path)).get(key) if (args.kind in ("pairs", "stream") and os.path.exists(path)) else None
         except Exception:
             entry = None
         if entry is None:
@@ -458,8 +458,10 @@ def main():
                 roofline["traffic_correction"] = {
                     "fetch_factor": entry["fetch_correction"], "fetch_counter_bytes": entry["fetch_counter_bytes"],
                     "write_bytes": entry["write_bytes"],
-                    "why": "FETCH_SIZE tallies 128-byte lines at 64 bytes on gfx950; calibrated on this kernel's own staging "
-                           "pattern: profiles/r03_fetch_calibration.txt"}
+                    "why": ("FETCH_SIZE tallies 128-byte lines at 64 bytes on gfx950; calibrated on this kernel's own staging "
+                            "pattern: profiles/r03_fetch_calibration.txt") if dom == "fast" else
+                           ("FETCH_SIZE tallies 128-byte lines at 64 bytes on gfx950 (factor calibrated on the FAST kernel's line-sized "
+                            "reads, profiles/r03_fetch_calibration.txt; an upper bound for this kernel's shorter reads)")}
             else:                     # a round-2 record: raw counter sum
                 roofline["traffic"] = entry
             roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / max(by, 1), 3)
@@ -495,7 +497,7 @@ def main():
     # this workload) against this run's step time: what "rocprof HBM GB/s against the chip's peak" reads for the path
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        ent = tj.get("step@%dx%dx%d_n%d_c%d" % (w, h, B, nfeat, args.channels)) if args.kind == "pairs" else None
+        ent = tj.get("step@%dx%dx%d_n%d_c%d" % (w, h, B, nfeat, args.channels)) if args.kind in ("pairs", "stream") else None
     except Exception:
         ent = None
     if ent:

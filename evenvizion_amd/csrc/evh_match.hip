@@ -5,6 +5,8 @@
 #include "evh_internal.h"
 #include "evh_match.h"
 #include <cfloat>
+#include <climits>
+#include <cstdlib>
 
 namespace {
 
@@ -105,6 +107,161 @@ __global__ __launch_bounds__(256) void k_knn2(EvhKnnArgs A) {
     if (act) {
       oidx[2 * qi] = i0; oidx[2 * qi + 1] = i1;
       od2[2 * qi] = b0; od2[2 * qi + 1] = b1;
+    }
+  }
+}
+
+// ---- the same 2-NN over 128-byte rows on the matrix cores (round 4) -------------------------------------------------------
+// SIFT at 720p is 25 000 x 25 000 rows per pair: 85 G byte products, 1.06 ms per pair with v_dot4 above.  The Gram matrix is
+// an integer GEMM, so v_mfma_i32_32x32x32_i8 computes it EXACTLY: with a = t - 128 (= t ^ 0x80) and b = 127 - q (= q ^ 0x7F)
+// as signed bytes,  sum a.b = 127 St + 128 Sq - 2 080 768 - q.t,  hence
+//     D = |q|^2 + |t|^2 - 2 q.t = [ |t|^2 - 254 St ] + 2 sum a.b + [ |q|^2 - 256 Sq + 4 161 536 ] = T(t) + 2 acc + C(q).
+// Trains are the A operand (rows of the 32x32 result), queries the B operand (column = lane & 31), so a lane owns ONE query
+// and sees 16 trains of a tile in its 16 accumulators; lane l and l + 32 split the 32 trains of a tile between them and are
+// merged once at the end under (distance class, index) -- the serial strict insertion keeps exactly the first two under that
+// order.  floor(T / 2) is the C-in of the first MFMA (read from LDS straight into the accumulators), so the epilogue of a
+// tile is a 15-instruction minimum and ONE compare against ceil((best2 - C) / 2): 2 e' >= best2 - C  =>  D >= best2, reject;
+// everything that passes takes the exact path (D rebuilt with T's parity bit, dist_lt as in k_knn2).  A workgroup stages 64
+// train rows per barrier (XOR-swizzled 16-byte slots: ds_read_b128 without bank conflicts) for 4 waves x 128 queries.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+#define KM_ROWS 64
+#define KM_QB 4
+#define KM_WQ (32 * KM_QB)
+#define KM_GQ (4 * KM_WQ)
+struct KmStage {
+  alignas(16) uint8_t rows[KM_ROWS * 128];
+  alignas(16) int th[KM_ROWS];      // floor(T / 2)
+  alignas(16) int tf[KM_ROWS];      // T (parity used by the exact path); rows past the end: 0x3FFFFFFE
+};
+
+__device__ __forceinline__ int min16(const v16i& a) {
+  const int m0 = min(min(a[0], a[1]), min(a[2], a[3])), m1 = min(min(a[4], a[5]), min(a[6], a[7]));
+  const int m2 = min(min(a[8], a[9]), min(a[10], a[11])), m3 = min(min(a[12], a[13]), min(a[14], a[15]));
+  return min(min(m0, m1), min(m2, m3));
+}
+// (d, i) before (e, j) in the operator's order: smaller distance class first, then the lower train index
+__device__ __forceinline__ bool knn_before(uint32_t d, int i, uint32_t e, int j) {
+  return dist_lt(d, e) || (!dist_lt(e, d) && i < j);
+}
+
+__global__ __launch_bounds__(256) void k_knn2_mfma128(EvhKnnArgs A) {
+  __shared__ KmStage S[2];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int qs = A.q_slot0 + p * A.q_slot_step, ts = A.t_slot0 + p * A.t_slot_step;
+  const int nq = A.nq_arr ? A.nq_arr[qs] : A.nq_fixed;
+  const int nt = A.nt_arr ? A.nt_arr[ts] : A.nt_fixed;
+  const uint4* Q = reinterpret_cast<const uint4*>(A.q + (int64_t)qs * A.slot_bytes);
+  const uint4* T = reinterpret_cast<const uint4*>(A.t + (int64_t)ts * A.slot_bytes);
+  int32_t* oidx = A.idx + (int64_t)p * A.out_stride * 2;
+  uint32_t* od2 = A.d2 + (int64_t)p * A.out_stride * 2;
+  const int ntile = (nt + KM_ROWS - 1) / KM_ROWS;
+  for (int q0 = blockIdx.y * KM_GQ; q0 < nq; q0 += KM_GQ * gridDim.y) {      // workgroup-uniform bounds
+    v4i bq[KM_QB][4];
+    int Cq[KM_QB], thr[KM_QB], i0[KM_QB], i1[KM_QB];
+    uint32_t b0[KM_QB], b1[KM_QB];
+#pragma unroll
+    for (int b = 0; b < KM_QB; b++) {
+      const int qi = q0 + wave * KM_WQ + 32 * b + r;
+      uint32_t s1 = 0, s2 = 0;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const uint4 x = qi < nq ? Q[8 * qi + 2 * s + h] : make_uint4(0, 0, 0, 0);
+        s1 = dot4(x.x, 0x01010101u, s1); s1 = dot4(x.y, 0x01010101u, s1); s1 = dot4(x.z, 0x01010101u, s1); s1 = dot4(x.w, 0x01010101u, s1);
+        s2 = dot4(x.x, x.x, s2); s2 = dot4(x.y, x.y, s2); s2 = dot4(x.z, x.z, s2); s2 = dot4(x.w, x.w, s2);
+        bq[b][s] = v4i{(int)(x.x ^ 0x7F7F7F7Fu), (int)(x.y ^ 0x7F7F7F7Fu), (int)(x.z ^ 0x7F7F7F7Fu), (int)(x.w ^ 0x7F7F7F7Fu)};
+      }
+      s1 += (uint32_t)__shfl_xor((int)s1, 32); s2 += (uint32_t)__shfl_xor((int)s2, 32);     // the other half of the row
+      Cq[b] = (int)s2 - 256 * (int)s1 + 4161536;
+      thr[b] = INT_MAX; b0[b] = 0xFFFFFFFFu; b1[b] = 0xFFFFFFFFu; i0[b] = -1; i1[b] = -1;
+    }
+    uint4 g[2];
+    auto gload = [&](int t0) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int i = tid + 256 * k, gr = t0 + (i >> 3);
+        g[k] = gr < nt ? T[8 * gr + (i & 7)] : make_uint4(0, 0, 0, 0);
+      }
+    };
+    auto lstore = [&](KmStage& st, int t0) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int i = tid + 256 * k, row = i >> 3, c = i & 7;
+        const uint4 x = g[k];
+        uint32_t s1 = 0, s2 = 0;
+        s1 = dot4(x.x, 0x01010101u, s1); s1 = dot4(x.y, 0x01010101u, s1); s1 = dot4(x.z, 0x01010101u, s1); s1 = dot4(x.w, 0x01010101u, s1);
+        s2 = dot4(x.x, x.x, s2); s2 = dot4(x.y, x.y, s2); s2 = dot4(x.z, x.z, s2); s2 = dot4(x.w, x.w, s2);
+        int t = (int)s2 - 254 * (int)s1;
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+        *reinterpret_cast<uint4*>(&st.rows[row * 128 + ((c ^ ((row >> 1) & 7)) << 4)]) =
+            make_uint4(x.x ^ 0x80808080u, x.y ^ 0x80808080u, x.z ^ 0x80808080u, x.w ^ 0x80808080u);
+        if (c == 0) {
+          const int tfull = t0 + row < nt ? t : 0x3FFFFFFE;
+          st.tf[row] = tfull; st.th[row] = tfull >> 1;
+        }
+      }
+    };
+    __syncthreads();                                   // the previous query block is done with both stages
+    if (ntile > 0) { gload(0); lstore(S[0], 0); }
+    __syncthreads();
+    for (int it = 0; it < ntile; it++) {
+      const int t0 = it * KM_ROWS;
+      KmStage& st = S[it & 1];
+      if (it + 1 < ntile) gload(t0 + KM_ROWS);
+      for (int sub = 0; sub < 2; sub++) {
+        const int row = 32 * sub + r;
+        v4i a[4], t4[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          a[s] = *reinterpret_cast<const v4i*>(&st.rows[row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4)]);
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) t4[gq] = *reinterpret_cast<const v4i*>(&st.th[32 * sub + 8 * gq + 4 * h]);
+#pragma unroll
+        for (int b = 0; b < KM_QB; b++) {
+          v16i acc;
+#pragma unroll
+          for (int e = 0; e < 16; e++) acc[e] = t4[e >> 2][e & 3];
+#pragma unroll
+          for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[b][s], acc, 0, 0, 0);
+          const int m = min16(acc);
+          if (__ballot(m < thr[b]) != 0ull) {          // rare after the first tiles: some lane may have a new best two
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+              const int mg = min(min(acc[4 * gq], acc[4 * gq + 1]), min(acc[4 * gq + 2], acc[4 * gq + 3]));
+              if (__ballot(mg < thr[b]) == 0ull) continue;
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const int e1 = acc[4 * gq + j];
+                const int lrow = 32 * sub + 8 * gq + 4 * h + j, gi = t0 + lrow;
+                if (e1 < thr[b] && gi < nt) {
+                  const uint32_t d = (uint32_t)(2 * e1 + (st.tf[lrow] & 1) + Cq[b]);
+                  if (dist_lt(d, b0[b])) { b1[b] = b0[b]; i1[b] = i0[b]; b0[b] = d; i0[b] = gi; }
+                  else if (dist_lt(d, b1[b])) { b1[b] = d; i1[b] = gi; }
+                  thr[b] = b1[b] == 0xFFFFFFFFu ? INT_MAX : ((int)b1[b] - Cq[b] + 1) >> 1;
+                }
+              }
+            }
+          }
+        }
+      }
+      if (it + 1 < ntile) lstore(S[(it + 1) & 1], t0 + KM_ROWS);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < KM_QB; b++) {
+      const uint32_t ob0 = (uint32_t)__shfl_xor((int)b0[b], 32), ob1 = (uint32_t)__shfl_xor((int)b1[b], 32);
+      const int oi0 = __shfl_xor(i0[b], 32), oi1 = __shfl_xor(i1[b], 32);
+      const bool other_first = knn_before(ob0, oi0, b0[b], i0[b]);
+      const uint32_t f_d = other_first ? ob0 : b0[b]; const int f_i = other_first ? oi0 : i0[b];
+      const uint32_t c1d = other_first ? b0[b] : ob0; const int c1i = other_first ? i0[b] : oi0;
+      const uint32_t c2d = other_first ? ob1 : b1[b]; const int c2i = other_first ? oi1 : i1[b];
+      const bool two = knn_before(c2d, c2i, c1d, c1i);
+      const int qi = q0 + wave * KM_WQ + 32 * b + r;
+      if (h == 0 && qi < nq) {
+        oidx[2 * qi] = f_i; oidx[2 * qi + 1] = two ? c2i : c1i;
+        od2[2 * qi] = f_d; od2[2 * qi + 1] = two ? c2d : c1d;
+      }
     }
   }
 }
@@ -517,7 +674,10 @@ int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs) {
   // chunks of 256 queries in grid.y, bounded by the largest possible query count
   const int nq_max = A.nq_arr ? A.out_stride : A.nq_fixed;
   const int chunks = std::max(1, std::min((nq_max + 255) / 256, 64));
-  if (A.desc_bytes == 128) hipLaunchKernelGGL((k_knn2<8, 128>), dim3(npairs, chunks), dim3(256), 0, c->stream, A);
+  static const bool dot4_form = getenv("EVH_KNN_DOT4") != nullptr;      // A/B switch: the v_dot4 kernel for 128-byte rows too
+  if (A.desc_bytes == 128 && !A.hamming && !dot4_form)
+    hipLaunchKernelGGL(k_knn2_mfma128, dim3(npairs, std::max(1, std::min((nq_max + KM_GQ - 1) / KM_GQ, 64))), dim3(256), 0, c->stream, A);
+  else if (A.desc_bytes == 128) hipLaunchKernelGGL((k_knn2<8, 128>), dim3(npairs, chunks), dim3(256), 0, c->stream, A);
   else hipLaunchKernelGGL((k_knn2<2, MT_TILE>), dim3(npairs, chunks), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
   return EVH_SUCCESS;

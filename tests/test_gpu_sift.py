@@ -493,6 +493,51 @@ def test_byte_matcher_on_128_byte_rows_ties_after_sqrt():
         c.close()
 
 
+@pytest.mark.parametrize("nq,nt,kind", [(1, 1, "rand"), (2, 1, "rand"), (1, 2, "rand"), (31, 63, "rand"), (33, 65, "edge"), (511, 700, "rand"),
+                                        (513, 129, "dup"), (1500, 3000, "rand"), (700, 2050, "edge"), (129, 64, "dup")])
+def test_byte_matcher_on_128_byte_rows_matrix_core_form(nq, nt, kind):
+    """k_knn2_mfma128: the Gram matrix of 128-byte rows on v_mfma_i32_32x32x32_i8 with the bias trick (t - 128, 127 - q) must
+    give the exact integer squared distances and the operator's ranking -- ragged sizes around the 32 / 64 / 512 tile edges,
+    rows of 0s and 255s (the extremes of the signed-byte bias), duplicated train rows (equal distances: the lower index wins,
+    also across the two lanes that share a query and across tiles).  Checker: exact int64 distances in numpy, stable argsort
+    (all D here are below 2^22, where the float32 sqrt ranking is the integer ranking), and the float matcher of the oracle."""
+    from evenvizion_amd._lib import Context
+    rng = np.random.default_rng(nq * 7919 + nt)
+    if kind == "edge":
+        q = rng.choice(np.array([0, 255, 1, 254, 128, 127], np.uint8), (nq, 128))
+        t = rng.choice(np.array([0, 255, 1, 254, 128, 127], np.uint8), (nt, 128))
+        q[0] = 0; q[-1] = 255; t[0] = 255; t[-1] = 0
+        # keep D below 2^22: at most 60 saturated coordinates differ
+        t[:, 60:] = 100; q[:, 60:] = 100
+    else:
+        base = rng.integers(0, 256, (max(nt // 3, 1), 128))
+        t = np.clip(base[rng.integers(0, len(base), nt)] // 3 + rng.integers(0, 30, (nt, 128)), 0, 255).astype(np.uint8)
+        q = np.clip(base[rng.integers(0, len(base), nq)] // 3 + rng.integers(0, 30, (nq, 128)), 0, 255).astype(np.uint8)
+        if kind == "dup":                                # every train row occurs several times, far apart
+            t = t[np.arange(nt) % max(nt // 4, 1)]
+    D = ((q[:, None, :].astype(np.int64) - t[None, :, :].astype(np.int64)) ** 2).sum(-1)
+    assert D.max() < (1 << 22)
+    order = np.argsort(D, axis=1, kind="stable")[:, :2]
+    c = Context(device=0, max_w=64, max_h=64, max_features=500, max_frames=2)
+    try:
+        idx = torch.full((nq, 2), -7, dtype=torch.int32, device="cuda")
+        d2 = torch.zeros(nq, 2, dtype=torch.int32, device="cuda")
+        c.knn2(dev(q), dev(t), idx, d2)
+        c.synchronize()
+        gi, gd = idx.cpu().numpy(), d2.cpu().numpy().astype(np.uint32)
+    finally:
+        c.close()
+    assert np.array_equal(gi[:, 0], order[:, 0])
+    assert np.array_equal(gd[:, 0], np.take_along_axis(D, order[:, :1], 1)[:, 0].astype(np.uint32))
+    if nt >= 2:
+        assert np.array_equal(gi[:, 1], order[:, 1])
+        assert np.array_equal(gd[:, 1], np.take_along_axis(D, order[:, 1:2], 1)[:, 0].astype(np.uint32))
+        oi, od = O.knn2_f32(q.astype(np.float32), t.astype(np.float32))
+        assert np.array_equal(gi, oi) and np.array_equal(np.sqrt(gd.astype(np.float32)), od)
+    else:
+        assert (gi[:, 1] == -1).all() and (gd[:, 1] == 0xFFFFFFFF).all()
+
+
 def test_detector_slot_overflow_is_a_pair_status_in_the_fused_path():
     """A frame with more SIFT key points than evh_sift_enable reserved fails ITS pairs with EVH_PAIR_CAPACITY (6) in the
     fused multi-type entries -- never a silent truncation -- and only the pairs that touch it."""

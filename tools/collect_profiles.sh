@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'): rocprofv3 kernel stats + separate PMC passes of the
+# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh' and, as a second call, 'bash tools/collect_profiles.sh stream'): rocprofv3 kernel stats + separate PMC passes of the
 # default bench workload (under the profiler the synthetic pairs are generated in-process: --gen-procs 1, no child processes).  Raw output -> gpurun_out/prof/ ; tools/summarize_profiles.py turns it into profiles/*.
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -7,6 +7,17 @@ O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export EVH_BENCH_CACHE=/tmp/evh_bench_cache     # the 64 synthetic pairs are generated once (in parallel, outside the profiler)
+if [ "$1" = "stream" ]; then      # second call (gpurun's 1200 s limit): only the PMC passes of the stream workloads
+(cd $R && python bench.py --config 3 --steps 1 --warmup 1 --cpu-pairs 0 --skip-no-temporal > $O/prime3.json 2> $O/prime3.err)
+# FETCH_SIZE / WRITE_SIZE passes of the stream workloads (configs 3 and 5): per-step HBM bytes of the scan kernel and of the whole step
+(cd $R && python bench.py --config 5 --steps 1 --warmup 1 --cpu-pairs 0 --skip-no-temporal > $O/prime5.json 2> $O/prime5.err)
+for c in 3 5; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch$c -o fetch$c --output-format csv -- python3 $R/bench.py --config $c --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --skip-no-temporal > $O/fetch$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write$c -o write$c --output-format csv -- python3 $R/bench.py --config $c --steps 2 --warmup 1 --cpu-pairs 0 --gen-procs 1 --skip-no-temporal > $O/write$c.log 2>&1
+done
+echo stream-passes-done
+exit 0
+fi
 (cd $R && python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --skip-no-temporal > $O/prime.json 2> $O/prime.err)
 (cd $R && python bench.py --config 3 --steps 1 --warmup 1 --cpu-pairs 0 > $O/prime3.json 2> $O/prime3.err)   # primes the config-3 cache outside the profiler
 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --gen-procs 1 --unique 64 --skip-no-temporal > $O/stats.log 2>&1

@@ -92,12 +92,49 @@ for k in set(fetch) | set(write):
     if k.startswith("k_"):
         step_total += (FETCH_CORRECTION * 1024.0 * sum(fetch.get(k, [])) + 1024.0 * sum(write.get(k, []))) / steps
 if fast_fetch > 0:
-    json.dump({"step@1280x720x1024_n500_c3": {"hbm_bytes_per_step": int(step_total), "source": "profiles/%s_pmc_hbm_traffic.csv (all k_* kernels of a step)" % tag},
+    try:
+        prev = json.load(open(os.path.join(out, "traffic.json")))
+    except Exception:
+        prev = {}
+    json.dump({**prev, "step@1280x720x1024_n500_c3": {"hbm_bytes_per_step": int(step_total), "source": "profiles/%s_pmc_hbm_traffic.csv (all k_* kernels of a step)" % tag},
                "fast@1280x720x1024_n500_c3": {"fetch_counter_bytes": int(fast_fetch), "write_bytes": int(fast_write),
                                               "fetch_correction": FETCH_CORRECTION,
                                               "hbm_bytes": int(FETCH_CORRECTION * fast_fetch + fast_write),
                                               "source": "profiles/%s_pmc_hbm_traffic.csv" % tag}},
               open(os.path.join(out, "traffic.json"), "w"))
+
+# 2b. stream workloads (bench.py --config 3 / 5): bytes per step of the scan kernel group and of every kernel, 3 launches of a
+#     step group per pass (1 warm-up + 2 steps)
+STREAMS = {3: (1280, 720, 48, 2000), 5: (3840, 2160, 16, 4000)}
+try:
+    tj_all = json.load(open(os.path.join(out, "traffic.json")))
+except Exception:
+    tj_all = {}
+for cfg_id, (sw, sh, sb, sn) in STREAMS.items():
+    fe = per_kernel("fetch%d" % cfg_id, "FETCH_SIZE")
+    wr = per_kernel("write%d" % cfg_id, "WRITE_SIZE")
+    if not fe or not wr:
+        continue
+    scan = [k for k in set(fe) | set(wr) if k.startswith("k_ransac_final")]
+    nstep = max([len(fe.get(k, [])) for k in scan] + [1])
+    sf = sum(1024.0 * sum(fe.get(k, [])) for k in scan) / nstep
+    sw_ = sum(1024.0 * sum(wr.get(k, [])) for k in scan) / nstep
+    tot = sum(FETCH_CORRECTION * 1024.0 * sum(fe.get(k, [])) + 1024.0 * sum(wr.get(k, [])) for k in set(fe) | set(wr) if k.startswith("k_")) / nstep
+    with open(os.path.join(out, tag + "_pmc_hbm_traffic_cfg%d.csv" % cfg_id), "w") as fo:
+        fo.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes): python3 bench.py --config %d --steps 2 --warmup 1 --cpu-pairs 0\n" % cfg_id)
+        fo.write("# stream of %d pairs per step at %dx%d, ORB %d; average bytes per kernel launch = counter x 1024; hbm_read = %.1f x fetch counter (profiles/r03_fetch_calibration.txt)\n" % (sb, sw, sh, sn, FETCH_CORRECTION))
+        fo.write("kernel,launches,fetch_counter_bytes_per_launch,hbm_read_bytes_per_launch,write_bytes_per_launch\n")
+        for k in sorted(set(fe) | set(wr)):
+            if k.startswith("k_"):
+                n = max(len(fe.get(k, [])), 1)
+                fo.write("%s,%d,%.0f,%.0f,%.0f\n" % (k, len(fe.get(k, [])), 1024.0 * sum(fe.get(k, [])) / n, FETCH_CORRECTION * 1024.0 * sum(fe.get(k, [])) / n,
+                                                   1024.0 * sum(wr.get(k, [])) / max(len(wr.get(k, [])), 1)))
+    tj_all["ransac_final@%dx%dx%d_n%d_c3" % (sw, sh, sb, sn)] = {
+        "fetch_counter_bytes": int(sf), "write_bytes": int(sw_), "fetch_correction": FETCH_CORRECTION, "hbm_bytes": int(FETCH_CORRECTION * sf + sw_),
+        "source": "profiles/%s_pmc_hbm_traffic_cfg%d.csv" % (tag, cfg_id)}
+    tj_all["step@%dx%dx%d_n%d_c3" % (sw, sh, sb, sn)] = {"hbm_bytes_per_step": int(tot), "source": "profiles/%s_pmc_hbm_traffic_cfg%d.csv (all k_* kernels of a step)" % (tag, cfg_id)}
+if tj_all:
+    json.dump(tj_all, open(os.path.join(out, "traffic.json"), "w"))
 
 # 3. SQ breakdown
 f = find("sq", "*counter_collection.csv")
