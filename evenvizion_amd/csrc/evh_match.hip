@@ -211,36 +211,46 @@ __global__ __launch_bounds__(256) void k_knn2_mfma128(EvhKnnArgs A) {
       if (it + 1 < ntile) gload(t0 + KM_ROWS);
       for (int sub = 0; sub < 2; sub++) {
         const int row = 32 * sub + r;
-        v4i a[4], t4[4];
+        v4i a[4];
+        v16i tc;                                       // floor(T / 2) of this lane's 16 rows: C-in of the first MFMA
 #pragma unroll
         for (int s = 0; s < 4; s++)
           a[s] = *reinterpret_cast<const v4i*>(&st.rows[row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4)]);
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) t4[gq] = *reinterpret_cast<const v4i*>(&st.th[32 * sub + 8 * gq + 4 * h]);
+        for (int gq = 0; gq < 4; gq++) {
+          const v4i t4 = *reinterpret_cast<const v4i*>(&st.th[32 * sub + 8 * gq + 4 * h]);
+          tc[4 * gq] = t4[0]; tc[4 * gq + 1] = t4[1]; tc[4 * gq + 2] = t4[2]; tc[4 * gq + 3] = t4[3];
+        }
 #pragma unroll
         for (int b = 0; b < KM_QB; b++) {
-          v16i acc;
+          v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[b][0], tc, 0, 0, 0);
 #pragma unroll
-          for (int e = 0; e < 16; e++) acc[e] = t4[e >> 2][e & 3];
-#pragma unroll
-          for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[b][s], acc, 0, 0, 0);
+          for (int s = 1; s < 4; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[b][s], acc, 0, 0, 0);
           const int m = min16(acc);
-          if (__ballot(m < thr[b]) != 0ull) {          // rare after the first tiles: some lane may have a new best two
+          if (__ballot(m < thr[b]) != 0ull) {          // some lane may have a new best two (every other tile early on, rare later)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
               const int mg = min(min(acc[4 * gq], acc[4 * gq + 1]), min(acc[4 * gq + 2], acc[4 * gq + 3]));
               if (__ballot(mg < thr[b]) == 0ull) continue;
+              const v4i par4 = *reinterpret_cast<const v4i*>(&st.tf[32 * sub + 8 * gq + 4 * h]);
 #pragma unroll
               for (int j = 0; j < 4; j++) {
                 const int e1 = acc[4 * gq + j];
-                const int lrow = 32 * sub + 8 * gq + 4 * h + j, gi = t0 + lrow;
-                if (e1 < thr[b] && gi < nt) {
-                  const uint32_t d = (uint32_t)(2 * e1 + (st.tf[lrow] & 1) + Cq[b]);
+                const int gi = t0 + 32 * sub + 8 * gq + 4 * h + j;
+                const bool cand = e1 < thr[b] && gi < nt;
+                const uint32_t d = (uint32_t)(2 * e1 + (par4[j] & 1) + Cq[b]);
+                // below 2^22 the float32 square roots are strictly ordered like the integers: plain compares.  A wave
+                // with a candidate at or above 2^22 (saturated rows only) takes the exact form for this element.
+                if (__ballot(cand && d >= (1u << 22)) == 0ull) {
+                  const bool lt0 = cand && d < b0[b], lt1 = cand && d < b1[b];
+                  b1[b] = lt0 ? b0[b] : lt1 ? d : b1[b]; i1[b] = lt0 ? i0[b] : lt1 ? gi : i1[b];
+                  b0[b] = lt0 ? d : b0[b]; i0[b] = lt0 ? gi : i0[b];
+                } else if (cand) {
                   if (dist_lt(d, b0[b])) { b1[b] = b0[b]; i1[b] = i0[b]; b0[b] = d; i0[b] = gi; }
                   else if (dist_lt(d, b1[b])) { b1[b] = d; i1[b] = gi; }
-                  thr[b] = b1[b] == 0xFFFFFFFFu ? INT_MAX : ((int)b1[b] - Cq[b] + 1) >> 1;
                 }
               }
+              thr[b] = b1[b] == 0xFFFFFFFFu ? INT_MAX : ((int)b1[b] - Cq[b] + 1) >> 1;
             }
           }
         }
@@ -676,7 +686,7 @@ int evh_launch_knn2(evh_ctx* c, const EvhKnnArgs& A, int npairs) {
   const int chunks = std::max(1, std::min((nq_max + 255) / 256, 64));
   static const bool dot4_form = getenv("EVH_KNN_DOT4") != nullptr;      // A/B switch: the v_dot4 kernel for 128-byte rows too
   if (A.desc_bytes == 128 && !A.hamming && !dot4_form)
-    hipLaunchKernelGGL(k_knn2_mfma128, dim3(npairs, std::max(1, std::min((nq_max + KM_GQ - 1) / KM_GQ, 64))), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_knn2_mfma128, dim3(npairs, std::max(1, std::min((nq_max + KM_GQ - 1) / KM_GQ, 256))), dim3(256), 0, c->stream, A);
   else if (A.desc_bytes == 128) hipLaunchKernelGGL((k_knn2<8, 128>), dim3(npairs, chunks), dim3(256), 0, c->stream, A);
   else hipLaunchKernelGGL((k_knn2<2, MT_TILE>), dim3(npairs, chunks), dim3(256), 0, c->stream, A);
   EVH_HIP(c, hipGetLastError());
