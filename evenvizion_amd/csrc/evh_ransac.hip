@@ -44,6 +44,9 @@ namespace {
 #define GL 16          // lanes per row
 #define MS 9           // row stride (doubles) of the matrices held in LDS, for N = 8 and N = 9
 #define TS 11          // stride (doubles) of one point's terms in the LDS tile
+#define TT (NL + 2)    // term-major tiles ([term][point], the single-problem stages): doubles between two terms' rows; 528
+                       // bytes, so that 16-byte reads of different terms fall on different bank slots
+typedef double d2_t __attribute__((ext_vector_type(2)));
 #define HB 2048        // displacement-histogram bins held in LDS (larger displacements take the quadratic path)
 
 // Ordering point between a cross-lane write and read of LDS / global scratch INSIDE one wavefront.  DS (and VMEM)
@@ -778,7 +781,7 @@ struct SolveLds {        // scratch of the single-problem stages (refit, LM): us
   double sc[8];          // scalars: S, Sd, lambda, lc, nu, rmax ...
   int ib[8];             // ints: proceed flags, counts
   int fast;              // EvhRansacArgs::fast_solver (set by the kernels before any solve)
-  double T[NL * TS];     // the 64-point tile
+  alignas(16) double T[NL * TS];     // the 64-point tile (16-byte LDS accesses: ds_read_b128 costs a quarter of the 8-byte forms)
   double P2[NL / 2 + 2]; // lm_eval: squared residuals of a tile, summed per pair of points (+ the two terms of an odd last point)
 };
 
@@ -795,21 +798,21 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
     const float4 r = rnext;                       // requested one tile ahead
     if (i + NL < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * (i + NL));
     if (i < count) {
-      T[lane * TS + 0] = r.z; T[lane * TS + 1] = r.w; T[lane * TS + 2] = r.x; T[lane * TS + 3] = r.y;
+      T[lane] = r.z; T[TT + lane] = r.w; T[2 * TT + lane] = r.x; T[3 * TT + lane] = r.y;
     }
     WSYNC();
     const int cnt = min(NL, count - c0);
     if (lane < 4) {
       int j = 0;
-      for (; j + 8 <= cnt; j += 8) {
-        double v[8];
+      for (; j + 16 <= cnt; j += 16) {
+        d2_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = T[(j + u) * TS + lane];
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const d2_t*>(T + lane * TT + j + 2 * u);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc += v[u];
+        for (int u = 0; u < 8; u++) { acc += v[u].x; acc += v[u].y; }
       }
-      for (; j < cnt; j++) acc += T[j * TS + lane];
+      for (; j < cnt; j++) acc += T[lane * TT + j];
     }
     WSYNC();
   }
@@ -823,21 +826,21 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
     const float4 r = rnext;                       // requested one tile ahead
     if (i + NL < count) rnext = *reinterpret_cast<const float4*>(rows + 4 * (i + NL));
     if (i < count) {
-      T[lane * TS + 0] = r.z; T[lane * TS + 1] = r.w; T[lane * TS + 2] = r.x; T[lane * TS + 3] = r.y;
+      T[lane] = r.z; T[TT + lane] = r.w; T[2 * TT + lane] = r.x; T[3 * TT + lane] = r.y;
     }
     WSYNC();
     const int cnt = min(NL, count - c0);
     if (lane < 4) {
       int j = 0;
-      for (; j + 8 <= cnt; j += 8) {
-        double v[8];
+      for (; j + 16 <= cnt; j += 16) {
+        d2_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = T[(j + u) * TS + lane];
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const d2_t*>(T + lane * TT + j + 2 * u);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 8; u++) dev += fabs(v[u] - mycen);
+        for (int u = 0; u < 8; u++) { dev += fabs(v[u].x - mycen); dev += fabs(v[u].y - mycen); }
       }
-      for (; j < cnt; j++) dev += fabs(T[j * TS + lane] - mycen);
+      for (; j < cnt; j++) dev += fabs(T[lane * TT + j] - mycen);
     }
     WSYNC();
   }
@@ -860,9 +863,9 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
     if (i < count) {
       const double x = (r.z - cmx) * smx, y = (r.w - cmy) * smy;
       const double X = (r.x - cMx) * sMx, Y = (r.y - cMy) * sMy;
-      double* t = T + lane * TS;
-      t[0] = X; t[1] = Y; t[2] = 1.0; t[3] = 0.0; t[4] = -x * X; t[5] = -x * Y; t[6] = -x;
-      t[7] = -y * X; t[8] = -y * Y; t[9] = -y;
+      double* t = T + lane;                                 // term j of this point at t[j * TT]
+      t[0] = X; t[TT] = Y; t[2 * TT] = 1.0; t[3 * TT] = 0.0; t[4 * TT] = -x * X; t[5 * TT] = -x * Y; t[6 * TT] = -x;
+      t[7 * TT] = -y * X; t[8 * TT] = -y * Y; t[9 * TT] = -y;
     }
     WSYNC();
     const int cnt = min(NL, count - c0);
@@ -870,19 +873,18 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
       // four points' operands requested before the first product: the compiler otherwise waits for the LDS after every
       // point (measured on lm_eval_mw's loops: one round trip per read group, 3x the time)
       int j = 0;
-      for (; j + 4 <= cnt; j += 4) {
-        const double* t = T + j * TS;
-        double a[4], b[4], c[4], d[4];
+      for (; j + 8 <= cnt; j += 8) {                        // eight points: four 16-byte reads per operand row
+        d2_t a[4], b[4], c[4], d[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = t[u * TS + lxj]; b[u] = t[u * TS + lxk]; c[u] = t[u * TS + lyj]; d[u] = t[u * TS + lyk]; }
+        for (int u = 0; u < 4; u++) {
+          a[u] = *reinterpret_cast<const d2_t*>(T + lxj * TT + j + 2 * u); b[u] = *reinterpret_cast<const d2_t*>(T + lxk * TT + j + 2 * u);
+          c[u] = *reinterpret_cast<const d2_t*>(T + lyj * TT + j + 2 * u); d[u] = *reinterpret_cast<const d2_t*>(T + lyk * TT + j + 2 * u);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) s += a[u] * b[u] + c[u] * d[u];
+        for (int u = 0; u < 4; u++) { s += a[u].x * b[u].x + c[u].x * d[u].x; s += a[u].y * b[u].y + c[u].y * d[u].y; }
       }
-      for (; j < cnt; j++) {
-        const double* t = T + j * TS;
-        s += t[lxj] * t[lxk] + t[lyj] * t[lyk];
-      }
+      for (; j < cnt; j++) s += T[lxj * TT + j] * T[lxk * TT + j] + T[lyj * TT + j] * T[lyk * TT + j];
     }
     WSYNC();
   }
@@ -1265,7 +1267,7 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
 // LANES: the hypothesis phase gives every LANE its own hypothesis (jacobi_lanes9) instead of every 16-lane row -- the
 // fixed-iteration mode, where thousands of hypotheses are evaluated and throughput counts; 23 KB of LDS per wave.
 template <int NW, bool LANES>
-struct BlockLds {
+struct alignas(16) BlockLds {
   RowMat m[LANES ? 1 : NW][NG];
   SolveLds s;
   int hyp[2][LANES ? NW * NL : NW * NG];    // per hypothesis of a chunk: valid << 31 | model << 30 | inlier count (double-buffered)
@@ -1302,7 +1304,11 @@ struct BlockLds {
 #define MW_NS 24                         // single entries of J^T J
 #define MW_NP 11                         // pair entries: 3 of J^T J + 8 of J^T r
 #define MW_NPR (MW_NS + 2 * MW_NP)       // products per point
-#define MW_PROD (MW_SUB * MW_NPR)        // doubles per product buffer
+#define MW_PSTR (MW_SUB + 2)              // doubles between two products' rows: [product][point], 144 bytes -> ds_*_b128 of
+                                         // neighbouring lanes fall on different bank slots
+#define MW_PROD (MW_PSTR * MW_NPR)       // doubles per product buffer
+#define MW_TSTR (NL + 2)                 // doubles between two terms' rows of a tile: [term][point], 528 bytes (same reason)
+typedef double mw_d2 __attribute__((ext_vector_type(2)));
 #ifndef MW_MIN_ROWS
 #define MW_MIN_ROWS 512                   // fewer inlier rows: wave 0 alone (measured break-even ~300 rows)
 #endif
@@ -1331,13 +1337,18 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
   static_assert(NW == 4 && !LANES, "helper waves: the four-wave row form only");
   static_assert(sizeof(RowMat) * (NW * NG - 1) >= sizeof(double) * (MW_PROD + NL * TS) + 16, "buffer 0 + second tile");
   static_assert(sizeof(B.u) >= sizeof(double) * MW_PROD + 16, "buffer 1");
+  static_assert(NL * TS >= 10 * MW_TSTR, "a tile of terms, term-major");
+  static_assert(alignof(BlockLds<NW, LANES>) >= 16, "16-byte LDS accesses below");
   SolveLds& S = B.s;
   // (selects, not arrays of pointers: an indexed pointer array loses the LDS address space and turns every access into
   // a FLAT instruction -- measured 3x slower)
-  double* const prod0 = reinterpret_cast<double*>(&B.m[0][1]);
-  double* const prod1 = reinterpret_cast<double*>(&B.u);
-  double* const Tb0 = S.T;
+  // every buffer starts on a 16-byte boundary (the struct is 16-byte aligned; an odd multiple of 8 is skipped by one double)
+  typedef BlockLds<NW, LANES> BL;
+  double* const prod0 = reinterpret_cast<double*>(&B.m[0][1]) + ((offsetof(BL, m) + sizeof(RowMat)) % 16 ? 1 : 0);
+  double* const prod1 = reinterpret_cast<double*>(&B.u) + (offsetof(BL, u) % 16 ? 1 : 0);
+  double* const Tb0 = S.T + ((offsetof(BL, s) + offsetof(SolveLds, T)) % 16 ? 1 : 0);
   double* const Tb1 = prod0 + MW_PROD;
+  static_assert(MW_PROD % 2 == 0 && MW_PSTR % 2 == 0 && MW_TSTR % 2 == 0 && MW_SUB % 2 == 0, "16-byte rows");
 #define MW_PRODBUF(i) (((i) & 1) ? prod1 : prod0)
 #define MW_TERMBUF(i) (((i) & 1) ? Tb1 : Tb0)
   const int nsub = (count + MW_SUB - 1) / MW_SUB;
@@ -1390,10 +1401,10 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
           const double xi = (h0 * Mx + h1 * My + h2) * ww;
           const double yi = (h3 * Mx + h4 * My + h5) * ww;
           const double rx = xi - r.z, ry = yi - r.w;
-          double* t = MW_TERMBUF(n) + lane * TS;
-          t[8] = rx; t[9] = ry;
-          t[0] = Mx * ww; t[1] = My * ww; t[2] = ww; t[3] = 0.0;
-          t[4] = -Mx * ww * xi; t[5] = -My * ww * xi; t[6] = -Mx * ww * yi; t[7] = -My * ww * yi;
+          double* t = MW_TERMBUF(n) + lane;                          // term j of this point at t[j * MW_TSTR]
+          t[8 * MW_TSTR] = rx; t[9 * MW_TSTR] = ry;
+          t[0] = Mx * ww; t[MW_TSTR] = My * ww; t[2 * MW_TSTR] = ww; t[3 * MW_TSTR] = 0.0;
+          t[4 * MW_TSTR] = -Mx * ww * xi; t[5 * MW_TSTR] = -My * ww * xi; t[6 * MW_TSTR] = -Mx * ww * yi; t[7 * MW_TSTR] = -My * ww * yi;
           rmax = fmax(rmax, fabs(rx));
           rmax = fmax(rmax, fabs(ry));
           q0 = rx * rx; q1 = ry * ry;
@@ -1407,18 +1418,19 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
       }
     } else if (wave == 0) {
       if (k >= 0 && lane < MW_NS) {
-        const double* r = MW_PRODBUF(k) + lane;
+        const double* r = MW_PRODBUF(k) + lane * MW_PSTR;               // this entry's products of the step's 16 points
         const int cnt = min(MW_SUB, count - k * MW_SUB);
         if (cnt == MW_SUB) {
-          // all words requested before the first addition (left alone the compiler waits for every read in turn)
-          double v[MW_SUB];
+          // all words requested before the first addition (left alone the compiler waits for every read in turn); two
+          // points per ds_read_b128 (a quarter of the LDS cycles of the 8-byte reads: this loop was LDS-issue bound)
+          mw_d2 v[MW_SUB / 2];
 #pragma unroll
-          for (int q = 0; q < MW_SUB; q++) v[q] = r[q * MW_NPR];
+          for (int q = 0; q < MW_SUB / 2; q++) v[q] = *reinterpret_cast<const mw_d2*>(r + 2 * q);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < MW_SUB; q++) s += v[q];
+          for (int q = 0; q < MW_SUB / 2; q++) { s += v[q].x; s += v[q].y; }
         } else {
-          for (int q = 0; q < cnt; q++) s += r[q * MW_NPR];
+          for (int q = 0; q < cnt; q++) s += r[q];
         }
       }
       // the squared norm of tile n (pair sums left by wave 1 one step ago), in order, by a lane with nothing else to do
@@ -1429,29 +1441,30 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
       }
     } else if (wave == 3) {
       if (k >= 0 && lane < MW_NP) {
-        const double* r = MW_PRODBUF(k) + MW_NS + 2 * lane;              // (x, y) of point q at r[q * MW_NPR], +1
+        const double* rx = MW_PRODBUF(k) + (MW_NS + 2 * lane) * MW_PSTR;  // x products of the 16 points; y: the next row
+        const double* ry = rx + MW_PSTR;
         const int cnt = min(MW_SUB, count - k * MW_SUB);
         if (cnt == MW_SUB) {
-          double vx[MW_SUB], vy[MW_SUB];
+          mw_d2 vx[MW_SUB / 2], vy[MW_SUB / 2];
 #pragma unroll
-          for (int q = 0; q < MW_SUB; q++) { vx[q] = r[q * MW_NPR]; vy[q] = r[q * MW_NPR + 1]; }
+          for (int q = 0; q < MW_SUB / 2; q++) { vx[q] = *reinterpret_cast<const mw_d2*>(rx + 2 * q); vy[q] = *reinterpret_cast<const mw_d2*>(ry + 2 * q); }
           __builtin_amdgcn_sched_barrier(0);
           if (lane < 3) {
 #pragma unroll
-            for (int q = 0; q < MW_SUB; q++) { s += vx[q]; s += vy[q]; }
+            for (int q = 0; q < MW_SUB / 2; q++) { s += vx[q].x; s += vy[q].x; s += vx[q].y; s += vy[q].y; }
           } else {
 #pragma unroll
-            for (int q = 0; q < MW_SUB; q += 2) { s0 += vx[q]; s1 += vy[q]; s2 += vx[q + 1]; s3 += vy[q + 1]; }
+            for (int q = 0; q < MW_SUB / 2; q++) { s0 += vx[q].x; s1 += vy[q].x; s2 += vx[q].y; s3 += vy[q].y; }
           }
         } else {
           int q = 0;
           for (; q + 1 < cnt; q += 2) {
-            const double a = r[q * MW_NPR], b = r[q * MW_NPR + 1], c = r[(q + 1) * MW_NPR], d = r[(q + 1) * MW_NPR + 1];
+            const double a = rx[q], b = ry[q], c = rx[q + 1], d = ry[q + 1];
             if (lane < 3) { s += a; s += b; s += c; s += d; }
             else { s0 += a; s1 += b; s2 += c; s3 += d; }
           }
           if (q < cnt) {
-            const double a = r[q * MW_NPR], b = r[q * MW_NPR + 1];
+            const double a = rx[q], b = ry[q];
             if (lane < 3) { s += a; s += b; }
             else { s0 += a; s0 += b; }
           }
@@ -1460,18 +1473,24 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
     } else {
       const int sub = k + 1;
       if (sub >= 0 && sub < nsub && lane < MW_NPR) {
-        const double* t = MW_TERMBUF(sub >> 2) + (sub & 3) * MW_SUB * TS;
-        double* out = MW_PRODBUF(sub) + lane;
+        const double* t = MW_TERMBUF(sub >> 2) + (sub & 3) * MW_SUB;     // term j of the step's point q at t[j * MW_TSTR + q]
+        double* out = MW_PRODBUF(sub) + lane * MW_PSTR;
         const int cnt = min(MW_SUB, count - sub * MW_SUB);
         if (cnt == MW_SUB) {
-          double va[MW_SUB], vb[MW_SUB];
+          mw_d2 va[MW_SUB / 2], vb[MW_SUB / 2];
 #pragma unroll
-          for (int q = 0; q < MW_SUB; q++) { va[q] = t[q * TS + ia]; vb[q] = t[q * TS + ib]; }
+          for (int q = 0; q < MW_SUB / 2; q++) {
+            va[q] = *reinterpret_cast<const mw_d2*>(t + ia * MW_TSTR + 2 * q);
+            vb[q] = *reinterpret_cast<const mw_d2*>(t + ib * MW_TSTR + 2 * q);
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < MW_SUB; q++) out[q * MW_NPR] = va[q] * vb[q];
+          for (int q = 0; q < MW_SUB / 2; q++) {
+            mw_d2 pr; pr.x = va[q].x * vb[q].x; pr.y = va[q].y * vb[q].y;
+            *reinterpret_cast<mw_d2*>(out + 2 * q) = pr;
+          }
         } else {
-          for (int q = 0; q < cnt; q++) out[q * MW_NPR] = t[q * TS + ia] * t[q * TS + ib];
+          for (int q = 0; q < cnt; q++) out[q] = t[ia * MW_TSTR + q] * t[ib * MW_TSTR + q];
         }
       }
     }

@@ -503,15 +503,18 @@ __global__ __launch_bounds__(1024) void k_sift_dedup(SiftArgs A, int f0) {
 // bins (r, c, o), r, c in 1..4 of the padded 6 x 6 grid, o in 0..9: thread t < 160 owns one bin and adds, sample after
 // sample in raster order, the one of the eight trilinear shares that falls on it
 __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
-  __shared__ float s_vals[256 * 8];
-  __shared__ int s_base[256];
+  __shared__ float s_list[256 * 8];             // the chunk's shares, grouped by bin, in sample order inside a bin
+  __shared__ unsigned short s_pref[160 * 8];     // per bin and 32-sample word: shares of the bin in the words before
+  __shared__ int s_binbase[160];
+  __shared__ int s_wtot[4];
   __shared__ float s_hist[160];
   __shared__ float s_dst[128];
   __shared__ float s_scale;
   __shared__ unsigned s_map[160 * 8];            // per bin: which of the chunk's 256 samples fall on it
   const int gf = blockIdx.y, f = f0 + gf, ki = blockIdx.x, tid = threadIdx.x;
   if (ki >= A.count[f]) return;
-  for (int i = tid; i < 160 * 8; i += 256) s_map[i] = 0u;      // (made visible by the first barrier of the chunk loop)
+  for (int i = tid; i < 160 * 8; i += 256) s_map[i] = 0u;
+  __syncthreads();                                             // before any sample ORs its bits in
   const float* rec = A.kp + ((int64_t)f * A.cap + ki) * 8;
   const int koct = __float_as_int(rec[5]);
   int oct = koct & 255;
@@ -539,7 +542,6 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
   cos_t /= hist_width; sin_t /= hist_width;
   const int side = 2 * radius + 1, total = side * side;
   const float inv_side = 1.0f / (float)side;
-  const int br = 1 + tid / 40, bc = 1 + (tid / 10) % 4, bo = tid % 10;
   float acc = 0.f;
   for (int k0 = 0; k0 < total; k0 += 256) {
     const int k = k0 + tid;
@@ -581,15 +583,11 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
       }
     }
     // Which samples fall on which bin: a 256-bit map per bin, set by the samples themselves with LDS atomic ORs (order-free,
-    // so the result is deterministic); a bin thread then walks the set bits of its own map in ascending order = the
-    // samples in raster order, and adds their shares.  (Every bin thread testing every contributing sample cost twelve
-    // instructions per sample and thread, 95 % of the kernel; the walk now touches only the ~5 % that hit.)
-    s_base[tid] = base;
-    {
-      float* v = s_vals + tid * 8;
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[q] = vv[q];
-    }
+    // so the result is deterministic).  Round 4: the bin threads no longer walk their maps through two dependent LDS reads
+    // per hit (the busiest bin of a chunk -- key-point orientation = dominant gradient direction, so a few bins take most of
+    // the samples -- set the latency of the whole chunk, ~36 000 cycles).  Instead the maps are turned into RANKS: a bin's
+    // population per 32-sample word and a prefix over the 160 bins give every (sample, corner) the slot of its share in a
+    // per-bin list, in sample order = raster order; the bin thread then adds a contiguous list with all loads in flight.
     if (base >= 0) {
       const int rb = base >> 16, cb = (base >> 8) & 255, ob = base & 255;      // r0 + 1, c0 + 1, o0
       const unsigned word = (unsigned)tid >> 5, bit = 1u << (tid & 31);
@@ -600,19 +598,54 @@ __global__ __launch_bounds__(256) void k_sift_desc(SiftArgs A, int f0) {
       }
     }
     __syncthreads();
-    if (tid < 160) {
+    int total = 0;
+    if (tid < 160) {                                     // population of the bin's words, exclusive prefix inside the bin
 #pragma unroll
       for (int w = 0; w < 8; w++) {
-        unsigned bits = s_map[tid * 8 + w];
-        if (bits) s_map[tid * 8 + w] = 0u;                                       // clean for the next chunk
-        while (bits) {
-          const int s = w * 32 + (__ffs((int)bits) - 1);
-          bits &= bits - 1u;
-          const int b = s_base[s];
-          const int dr = br - (b >> 16), dc = bc - ((b >> 8) & 255), dq = bo - (b & 255);
-          acc += s_vals[s * 8 + dr * 4 + dc * 2 + dq];
+        const unsigned m = s_map[tid * 8 + w];
+        s_pref[tid * 8 + w] = (unsigned short)total;
+        total += __popc(m);
+      }
+    }
+    // exclusive prefix of `total` over the 160 bins (waves 0..2): wave scan, then the wave totals
+    int incl = total;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) { const int v = __shfl_up(incl, sh); if ((tid & 63) >= sh) incl += v; }
+    if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+    __syncthreads();
+    int mybase = incl - total;
+    if (tid >= 64) mybase += s_wtot[0];
+    if (tid >= 128) mybase += s_wtot[1];
+    if (tid < 160) s_binbase[tid] = mybase;
+    __syncthreads();
+    if (base >= 0) {
+      const int rb = base >> 16, cb = (base >> 8) & 255, ob = base & 255;
+      const unsigned word = (unsigned)tid >> 5, below = (1u << (tid & 31)) - 1u;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int r = rb + (q >> 2), c = cb + ((q >> 1) & 1), o = ob + (q & 1);
+        if (r >= 1 && r <= 4 && c >= 1 && c <= 4) {
+          const int bin = (r - 1) * 40 + (c - 1) * 10 + o;
+          const int pos = s_binbase[bin] + (int)s_pref[bin * 8 + word] + __popc(s_map[bin * 8 + word] & below);
+          s_list[pos] = vv[q];
         }
       }
+    }
+    __syncthreads();
+    if (tid < 160) {
+#pragma unroll
+      for (int w = 0; w < 8; w++) s_map[tid * 8 + w] = 0u;                          // clean for the next chunk
+      const float* L = s_list + mybase;
+      int i = 0;
+      for (; i + 8 <= total; i += 8) {                   // all eight words requested before the first addition
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = L[i + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+      }
+      for (; i < total; i++) acc += L[i];
     }
     __syncthreads();
   }
