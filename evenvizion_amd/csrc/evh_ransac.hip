@@ -767,6 +767,9 @@ __device__ __forceinline__ int wave_sum(int v) {
 enum { PF_CALLS = 0, PF_HYP, PF_CHUNKS, PF_COMPACT, PF_REFIT, PF_LM, PF_LM_ITERS, PF_SOLVE8, PF_EVAL, PF_TOTAL, PF_ROT9,
        PF_ROT8, PF_SETUP, PF_RNG, PF_COUNT, PF_BARRIER, PF_REPLAY, PF_MW_W0, PF_MW_W1, PF_MW_W2, PF_MW_W3, PF_MW_WAIT, PF_MW_STEPS, PF_NSLOTS };
 __device__ __forceinline__ unsigned long long pf_now() { return __builtin_readcyclecounter(); }
+// inside loops: s_memtime is a scalar memory instruction -- its result is waited for with lgkmcnt(0), which also drains every
+// LDS read in flight -- so the counter is read only when the accounting is on (prof is wave-uniform)
+__device__ __forceinline__ unsigned long long pf_now_if(const unsigned long long* prof) { return prof ? __builtin_readcyclecounter() : 0ull; }
 __device__ __forceinline__ void pf_add(unsigned long long* prof, int slot, unsigned long long v) {
   if (prof && threadIdx.x == 0) atomicAdd(prof + slot, v);
 }
@@ -905,7 +908,7 @@ __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const
 // s_i = (sum_j u_i[j] b[j]) / w_i, lane j accumulates x[j] += s_i u_i[j] over i ascending.
 __device__ __forceinline__ void eig_solve8_wave(RowMat& M, int lane, const double* Ain /*LDS 64*/, const double* b /*LDS 8 or null*/,
                                 double* x /*LDS 8 or 64*/, unsigned long long* prof = nullptr) {
-  const unsigned long long pt0 = pf_now();
+  const unsigned long long pt0 = pf_now_if(prof);
   {
     const int i = lane >> 3, j = lane & 7;
     M.A[i * MS + j] = Ain[min(i, j) * 8 + max(i, j)];
@@ -951,7 +954,7 @@ __device__ __forceinline__ void eig_solve8_wave(RowMat& M, int lane, const doubl
     x[r * 8 + j] = acc;
   }
   WSYNC();
-  pf_add(prof, PF_SOLVE8, pf_now() - pt0);
+  pf_add(prof, PF_SOLVE8, pf_now_if(prof) - pt0);
 }
 
 // acc + v[0] + v[1] + ... + v[n-1] in that order, the words requested sixteen at a time (the compiler alone waits for the
@@ -1164,9 +1167,9 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   if (lane < 8) S.x[lane] = S.H[lane];
   WSYNC();
-  unsigned long long pe = pf_now();
+  unsigned long long pe = pf_now_if(prof);
   evalJ();
-  pf_add(prof, PF_EVAL, pf_now() - pe);
+  pf_add(prof, PF_EVAL, pf_now_if(prof) - pe);
   if (lane < 8) S.D[lane] = S.A8[lane * 8 + lane];
   if (lane == 0) { S.sc[2] = 1; S.sc[3] = 0.75; }  // lambda, lc
   WSYNC();
@@ -1179,18 +1182,18 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
     WSYNC();
     bool solved = false;
     if (S.fast) {
-      const unsigned long long pt0 = pf_now();
+      const unsigned long long pt0 = pf_now_if(prof);
       fast_solve8(lane, S.Ap, S.v, S.d, &S.ib[2]);
       WSYNC();
       solved = S.ib[2] != 0;
-      pf_add(prof, PF_SOLVE8, pf_now() - pt0);
+      pf_add(prof, PF_SOLVE8, pf_now_if(prof) - pt0);
     }
     if (!solved) eig_solve8_wave(M, lane, S.Ap, S.v, S.d, prof);
     if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
     WSYNC();
-    pe = pf_now();
+    pe = pf_now_if(prof);
     evalN();
-    pf_add(prof, PF_EVAL, pf_now() - pe);
+    pf_add(prof, PF_EVAL, pf_now_if(prof) - pe);
     // trial residual -> Sd, gain ratio R; lane 0 decides, the (rare) inverse is done by the whole wave
     if (lane == 0) {
       const double Rlo = 0.25, Rhi = 0.75;
@@ -1246,9 +1249,9 @@ __device__ __forceinline__ int lm_refine(SolveLds& S, RowMat& M, int lane, const
     if (accepted) {
       if (lane < 8) { const double t = S.x[lane]; S.x[lane] = S.xd[lane]; S.xd[lane] = t; }
       WSYNC();
-      pe = pf_now();
+      pe = pf_now_if(prof);
       evalJ();                                          // residuals / Jacobian at the accepted point (S = Sd again)
-      pf_add(prof, PF_EVAL, pf_now() - pe);
+      pf_add(prof, PF_EVAL, pf_now_if(prof) - pe);
     }
     iter++;
     // norm(r, INF) of the kept residual, norm(d, INF)
@@ -1383,7 +1386,7 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
   float4 rnext = make_float4(0, 0, 0, 0);
   unsigned long long pf_busy = 0, pf_wait = 0;       // cycle accounting: summed in registers, one atomic per pass
   for (int k = -2; k < nsub; k++) {
-    const unsigned long long pm0 = pf_now();
+    const unsigned long long pm0 = pf_now_if(prof);
     if (wave == 1) {
       // rows of the tile whose terms are due at the next step (or now, for the first tile)
       if (k == -2 || ((k + 3) & 3) == 0) {
@@ -1494,9 +1497,9 @@ __device__ __forceinline__ void lm_eval_mw(BlockLds<NW, LANES>& B, int wave, int
         }
       }
     }
-    const unsigned long long pm1 = pf_now();
+    const unsigned long long pm1 = pf_now_if(prof);
     __syncthreads();
-    pf_busy += pm1 - pm0; pf_wait += pf_now() - pm1;
+    pf_busy += pm1 - pm0; pf_wait += pf_now_if(prof) - pm1;
   }
   pf_add_wave(prof, PF_MW_W0 + wave, pf_busy);
   if (wave == 0) { pf_add(prof, PF_MW_WAIT, pf_wait); pf_add(prof, PF_MW_STEPS, nsub + 2); }
@@ -1602,7 +1605,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
                                       int force_max, uint8_t* mask, float* crow, int* info, unsigned long long* prof,
                                       double* lane_v /* LANES: this workgroup's NW * 81 * 64 doubles of global scratch */,
                                       const ScanPre* pre = nullptr /* force_max only */) {
-  const unsigned long long pf0 = pf_now();
+  const unsigned long long pf0 = pf_now_if(prof);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, gl = lane & 15;
   SolveLds& S = B.s;
   if (info && tid < 3) info[tid] = 0;
@@ -1661,7 +1664,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
   }
   while (!stop && iter < niters) {
     // every lane advances the generator identically through HC quadruples; the lanes of hypothesis h keep quadruple #h
-    const unsigned long long pr0 = pf_now();
+    const unsigned long long pr0 = pf_now_if(prof);
     int my[4] = {0, 1, 2, 3};
     for (int h = 0; h < HC; h++) {
       // four distinct indices, a duplicate is redrawn (getSubset's inner loop, straight-line)
@@ -1680,12 +1683,12 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
     }
     const bool valid = check_subset4(Mx, My, mx, my_);
     double H[9];
-    const unsigned long long ps0 = pf_now();
+    const unsigned long long ps0 = pf_now_if(prof);
     pf_add(prof, PF_RNG, ps0 - pr0);
     bool ok;
     if constexpr (LANES) ok = dlt4_lane(B.u.lmat + (wave * LM_ELEMS * NL + lane), lane_v + (wave * LV_ELEMS * NL + lane), valid, Mx, My, mx, my_, H);
     else ok = dlt4_rows(B.m[wave][row], lane, valid, Mx, My, mx, my_, H);
-    const unsigned long long ps1 = pf_now();
+    const unsigned long long ps1 = pf_now_if(prof);
     pf_add(prof, PF_SETUP, ps1 - ps0);
     int good = 0;
     {
@@ -1714,10 +1717,10 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
     }
     int* hyp = B.hyp[chunk & 1];
     if (LANES || gl == 0) hyp[myh] = (valid ? 0x80000000u : 0u) | (ok ? 0x40000000u : 0u) | (unsigned)good;
-    const unsigned long long ps2 = pf_now();
+    const unsigned long long ps2 = pf_now_if(prof);
     pf_add(prof, PF_COUNT, ps2 - ps1);
     __syncthreads();
-    const unsigned long long ps3 = pf_now();
+    const unsigned long long ps3 = pf_now_if(prof);
     pf_add(prof, PF_BARRIER, ps3 - ps2);
     // sequential replay in sample order (every thread, identically); the chunk's entries are fetched once into
     // registers (lane j holds entries j, j + 64, ...) and walked with v_readlane instead of one LDS round trip each
@@ -1751,11 +1754,11 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
       for (int i = 0; i < 9; i++) S.bestH[i] = H[i];
     }
     chunk++;
-    pf_add(prof, PF_REPLAY, pf_now() - ps3);
+    pf_add(prof, PF_REPLAY, pf_now_if(prof) - ps3);
   }
   __threadfence_block();
   __syncthreads();
-  const unsigned long long pf1 = pf_now();
+  const unsigned long long pf1 = pf_now_if(prof);
   pf_add(prof, PF_CALLS, 1); pf_add(prof, PF_HYP, pf1 - pf0); pf_add(prof, PF_CHUNKS, chunk);
   if (info && tid == 0) { info[0] = iter; info[1] = maxGood; }
   if (maxGood <= 0) return false;
@@ -1782,11 +1785,11 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
     WSYNC();
     if (lane < 9) S.H[lane] = S.bestH[lane];
     WSYNC();
-    const unsigned long long pf2 = pf_now();
+    const unsigned long long pf2 = pf_now_if(prof);
     pf_add(prof, PF_COMPACT, pf2 - pf1);
     if (ni > 0) {
       dlt_rows(S, B.m[0][0], lane, crow, ni, S.H, prof);  // keeps the RANSAC model when the refit is degenerate
-      const unsigned long long pf3 = pf_now();
+      const unsigned long long pf3 = pf_now_if(prof);
       pf_add(prof, PF_REFIT, pf3 - pf2);
       int it;
       if constexpr (NW == 4 && !LANES) {
@@ -1809,7 +1812,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
         it = lm_refine(S, B.m[0][0], lane, crow, ni, prof, [&]() { lm_eval(S, lane, crow, ni, S.x, true, 0, 1); },
                        [&]() { lm_eval(S, lane, crow, ni, S.xd, false, 5, 6); });
       }
-      pf_add(prof, PF_LM, pf_now() - pf3); pf_add(prof, PF_LM_ITERS, it);
+      pf_add(prof, PF_LM, pf_now_if(prof) - pf3); pf_add(prof, PF_LM_ITERS, it);
       if (info && lane == 0) info[2] = it;
     }
     if constexpr (NW == 4 && !LANES) {
@@ -1822,7 +1825,7 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
   }
   __threadfence_block();
   __syncthreads();
-  pf_add(prof, PF_TOTAL, pf_now() - pf0);
+  pf_add(prof, PF_TOTAL, pf_now_if(prof) - pf0);
   return true;
 }
 
