@@ -338,3 +338,32 @@ def test_introselect_statement_equals_libstdcxx(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, src])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("mismatches 0 of "), r.stdout + r.stderr
+
+
+def test_sift_filter_fusion_modes_differ_only_where_stated():
+    """evo_set_sift_blur_mode: 2 (the pinned split) fuses the multiply-adds of the float Gaussian filter in columns
+    [0, w & ~7) of the row pass and [0, w & ~15) of the column pass.  So against mode 1 (fusion everywhere) the FIRST blurred
+    image may differ only right of w & ~15, a width that is a multiple of 16 gives identical scale spaces, and mode 0 (no
+    fusion) differs from both nearly everywhere."""
+    rng = np.random.default_rng(3)
+    img = (S.make_pair(5, 96, 64)[0][:57, :53]).copy()          # doubled: 106 x 114 -> 106 & ~15 = 96
+    assert img.shape == (57, 53)
+    pyr = {}
+    try:
+        for m in (0, 1, 2):
+            O.set_sift_blur_mode(m)
+            pyr[m] = [p.copy() for p in O.sift_gauss_pyramid(img)]
+    finally:
+        O.set_sift_blur_mode(2)
+    assert O.get_sift_blur_mode() == 2
+    base1, base2 = pyr[1][0][0], pyr[2][0][0]                      # octave 0, layer 0: one blur of the doubled frame
+    assert base1.shape[1] == 106
+    assert np.array_equal(base1[:, :96], base2[:, :96]) and not np.array_equal(base1[:, 96:], base2[:, 96:])
+    assert (pyr[0][0][0] != base2).mean() > 0.3
+    wide = S.make_pair(6, 96, 64)[0][:40, :64].copy()             # doubled: 128 columns, octaves 128 / 64 / 32 / 16: all multiples of 16
+    try:
+        O.set_sift_blur_mode(1); a = O.sift_gauss_pyramid(wide)
+        O.set_sift_blur_mode(2); b = O.sift_gauss_pyramid(wide)
+    finally:
+        O.set_sift_blur_mode(2)
+    assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4]))
