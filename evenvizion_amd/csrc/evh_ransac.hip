@@ -788,9 +788,70 @@ struct SolveLds {        // scratch of the single-problem stages (refit, LM): us
   double P2[NL / 2 + 2]; // lm_eval: squared residuals of a tile, summed per pair of points (+ the two terms of an odd last point)
 };
 
+// ---- tolerance mode (EVH_SOLVER_FAST) of the refit's sums: lane-strided partial sums + a butterfly instead of the point-order
+// chains (see lm_eval_fast).  With a = (X, Y, 1): Lx = (a, 0, -x a), Ly = (0, a, -y a), so L^T L needs sum a_i a_j, sum x a_i a_j,
+// sum y a_i a_j and sum (x^2 + y^2) a_i a_j -- 24 sums instead of 45 chains.  The eigen-solve and the de-normalisation are shared.
+__device__ __forceinline__ double wave_sum_f64_(double v) {
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+  return v;
+}
+__device__ __forceinline__ bool dlt_rows_fast(RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */,
+                                              unsigned long long* prof) {
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (int i = lane; i < count; i += NL) {
+    const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+    c0 += r.z; c1 += r.w; c2 += r.x; c3 += r.y;
+  }
+  const double cmx = wave_sum_f64_(c0) / count, cmy = wave_sum_f64_(c1) / count, cMx = wave_sum_f64_(c2) / count, cMy = wave_sum_f64_(c3) / count;
+  c0 = c1 = c2 = c3 = 0;
+  for (int i = lane; i < count; i += NL) {
+    const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+    c0 += fabs(r.z - cmx); c1 += fabs(r.w - cmy); c2 += fabs(r.x - cMx); c3 += fabs(r.y - cMy);
+  }
+  double smx = wave_sum_f64_(c0), smy = wave_sum_f64_(c1), sMx = wave_sum_f64_(c2), sMy = wave_sum_f64_(c3);
+  if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return false;
+  smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+  double aa[6] = {0, 0, 0, 0, 0, 0}, xa[6] = {0, 0, 0, 0, 0, 0}, ya[6] = {0, 0, 0, 0, 0, 0}, qa[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = lane; i < count; i += NL) {
+    const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+    const double x = (r.z - cmx) * smx, y = (r.w - cmy) * smy;
+    const double X = (r.x - cMx) * sMx, Y = (r.y - cMy) * sMy;
+    const double p[6] = {X * X, X * Y, X, Y * Y, Y, 1.0};           // a_i a_j for (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    const double q = x * x + y * y;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { aa[k] += p[k]; xa[k] += x * p[k]; ya[k] += y * p[k]; qa[k] += q * p[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) { aa[k] = wave_sum_f64_(aa[k]); xa[k] = wave_sum_f64_(xa[k]); ya[k] = wave_sum_f64_(ya[k]); qa[k] = wave_sum_f64_(qa[k]); }
+  if (lane == 0) {
+    for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) M.A[i * MS + j] = 0.0;
+    const int ui[6] = {0, 0, 0, 1, 1, 2}, uj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int i = ui[k], j = uj[k];
+      M.A[i * MS + j] = aa[k]; M.A[j * MS + i] = aa[k];
+      M.A[(3 + i) * MS + 3 + j] = aa[k]; M.A[(3 + j) * MS + 3 + i] = aa[k];
+      M.A[(6 + i) * MS + 6 + j] = qa[k]; M.A[(6 + j) * MS + 6 + i] = qa[k];
+      M.A[i * MS + 6 + j] = -xa[k]; M.A[j * MS + 6 + i] = -xa[k]; M.A[(6 + j) * MS + i] = -xa[k]; M.A[(6 + i) * MS + j] = -xa[k];
+      M.A[(3 + i) * MS + 6 + j] = -ya[k]; M.A[(3 + j) * MS + 6 + i] = -ya[k]; M.A[(6 + j) * MS + 3 + i] = -ya[k]; M.A[(6 + i) * MS + 3 + j] = -ya[k];
+    }
+  }
+  WSYNC();
+  pf_add(prof, PF_ROT9, jacobi_one<9>(M, lane));
+  if (lane == 0) {
+    double H[9];
+    dlt_finish(M, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
+    for (int i = 0; i < 9; i++) Hout[i] = H[i];
+  }
+  WSYNC();
+  return true;
+}
+
 // ---- single-problem normalised DLT on `count` rows (ax,ay,bx,by): sums in row order, one lane per sum; wave 0 ------
 __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */,
                                          unsigned long long* prof = nullptr) {
+  if (S.fast && count > 4) return dlt_rows_fast(M, lane, rows, count, Hout, prof);
   double* T = S.T;
   // centroids: lanes 0..3 own cm.x, cm.y, cM.x, cM.y  (m = b columns, M = a columns)
   double acc = 0;
@@ -1070,6 +1131,79 @@ __device__ __forceinline__ void lm_eval(SolveLds& S, int lane, const float* rows
   if (withJ && lane < 36) { S.A8[ei * 8 + ej] = s; S.A8[ej * 8 + ei] = s; }
   if (withJ && lane >= 36 && lane < 44) S.v[vi] = (s0 + s1 + s2 + s3) * 1.0;
   if (lane == 44) { S.sc[slotS] = nrm; S.sc[slotR] = rmax; }
+  WSYNC();
+}
+
+// ---- tolerance mode (EVH_SOLVER_FAST): the same sums WITHOUT the operator's point order.  Every lane of wave 0 takes the
+// points lane, lane + 64, ... and keeps its own partial sums in registers, a butterfly over the wave adds them: the 2N-long
+// dependent chains of the exact form (8.4 cycles per addition, 0.7 M cycles per pair on the default detector list) become
+// N / 64 independent steps and a 6-level tree.  J's rows are (t0 t1 t2 0 0 0 t4 t5) and (0 0 0 t0 t1 t2 t6 t7): 21 distinct
+// entries of J^T J (the (3..5, 3..5) block repeats the (0..2, 0..2) block), 8 of J^T r, the squared norm, max |r|.
+// Results differ from the exact form in the last digits (tests/test_gpu_parity.py::test_fast_solver_mode states the bars).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+  return v;
+}
+__device__ __forceinline__ void lm_eval_fast(SolveLds& S, int lane, const float* rows, int count, const double* h, bool withJ, int slotS,
+                                             int slotR) {
+  const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7];
+  double xx[6] = {0, 0, 0, 0, 0, 0};        // sum t_i t_j, (i, j) = (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+  double xh[6] = {0, 0, 0, 0, 0, 0};        // sum t_i t4, t_i t5        (rows 0..2 against columns 6, 7)
+  double yh[6] = {0, 0, 0, 0, 0, 0};        // sum t_i t6, t_i t7        (rows 3..5 against columns 6, 7)
+  double hh[3] = {0, 0, 0};                 // (6,6) (6,7) (7,7)
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double nrm = 0, rmax = 0;
+  for (int i = lane; i < count; i += NL) {
+    const float4 r = *reinterpret_cast<const float4*>(rows + 4 * i);
+    const double Mx = r.x, My = r.y;
+    double ww = h6 * Mx + h7 * My + 1.;
+    ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+    const double xi = (h0 * Mx + h1 * My + h2) * ww;
+    const double yi = (h3 * Mx + h4 * My + h5) * ww;
+    const double rx = xi - r.z, ry = yi - r.w;
+    rmax = fmax(rmax, fmax(fabs(rx), fabs(ry)));
+    nrm += rx * rx + ry * ry;
+    if (withJ) {
+      const double t0 = Mx * ww, t1 = My * ww, t2 = ww;
+      const double t4 = -t0 * xi, t5 = -t1 * xi, t6 = -t0 * yi, t7 = -t1 * yi;
+      xx[0] += t0 * t0; xx[1] += t0 * t1; xx[2] += t0 * t2; xx[3] += t1 * t1; xx[4] += t1 * t2; xx[5] += t2 * t2;
+      xh[0] += t0 * t4; xh[1] += t0 * t5; xh[2] += t1 * t4; xh[3] += t1 * t5; xh[4] += t2 * t4; xh[5] += t2 * t5;
+      yh[0] += t0 * t6; yh[1] += t0 * t7; yh[2] += t1 * t6; yh[3] += t1 * t7; yh[4] += t2 * t6; yh[5] += t2 * t7;
+      hh[0] += t4 * t4 + t6 * t6; hh[1] += t4 * t5 + t6 * t7; hh[2] += t5 * t5 + t7 * t7;
+      v[0] += t0 * rx; v[1] += t1 * rx; v[2] += t2 * rx; v[3] += t0 * ry; v[4] += t1 * ry; v[5] += t2 * ry;
+      v[6] += t4 * rx + t6 * ry; v[7] += t5 * rx + t7 * ry;
+    }
+  }
+  nrm = wave_sum_f64(nrm);
+  for (int sft = 32; sft > 0; sft >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, sft));
+  if (withJ) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) { xx[k] = wave_sum_f64(xx[k]); xh[k] = wave_sum_f64(xh[k]); yh[k] = wave_sum_f64(yh[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) hh[k] = wave_sum_f64(hh[k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = wave_sum_f64(v[k]);
+    if (lane == 0) {
+      double* A = S.A8;
+      for (int k = 0; k < 64; k++) A[k] = 0.0;
+      const int ui[6] = {0, 0, 0, 1, 1, 2}, uj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        A[ui[k] * 8 + uj[k]] = xx[k]; A[uj[k] * 8 + ui[k]] = xx[k];
+        A[(3 + ui[k]) * 8 + 3 + uj[k]] = xx[k]; A[(3 + uj[k]) * 8 + 3 + ui[k]] = xx[k];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        A[i * 8 + 6] = xh[2 * i]; A[6 * 8 + i] = xh[2 * i]; A[i * 8 + 7] = xh[2 * i + 1]; A[7 * 8 + i] = xh[2 * i + 1];
+        A[(3 + i) * 8 + 6] = yh[2 * i]; A[6 * 8 + 3 + i] = yh[2 * i]; A[(3 + i) * 8 + 7] = yh[2 * i + 1]; A[7 * 8 + 3 + i] = yh[2 * i + 1];
+      }
+      A[6 * 8 + 6] = hh[0]; A[6 * 8 + 7] = hh[1]; A[7 * 8 + 6] = hh[1]; A[7 * 8 + 7] = hh[2];
+#pragma unroll
+      for (int k = 0; k < 8; k++) S.v[k] = v[k];
+    }
+  }
+  if (lane == 0) { S.sc[slotS] = nrm; S.sc[slotR] = rmax; }
   WSYNC();
 }
 
@@ -1796,12 +1930,14 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
         // the passes with the Jacobian run on all four waves: post the command, meet the helpers at the barrier
         // (from MW_MIN_ROWS rows on: below that the extra barriers cost what the helpers save)
         it = lm_refine(S, B.m[0][0], lane, crow, ni, prof, [&]() {
+          if (S.fast) { lm_eval_fast(S, lane, crow, ni, S.x, true, 0, 1); return; }
           if (ni < MW_MIN_ROWS) { lm_eval(S, lane, crow, ni, S.x, true, 0, 1); return; }
           if (lane == 0) { S.ib[4] = 1; S.ib[5] = ni; }
           __threadfence_block();
           __syncthreads();
           lm_eval_mw<NW, LANES>(B, 0, lane, crow, ni, prof);
         }, [&]() {
+          if (S.fast) { lm_eval_fast(S, lane, crow, ni, S.xd, false, 5, 6); return; }
           if (ni < MW_MIN_ROWS) { lm_eval(S, lane, crow, ni, S.xd, false, 5, 6); return; }
           if (lane == 0) { S.ib[4] = 2; S.ib[5] = ni; }
           __threadfence_block();
@@ -1809,8 +1945,9 @@ __device__ __forceinline__ bool find_homography_block(BlockLds<NW, LANES>& B, co
           lm_eval_noj_mw<NW, LANES>(B, 0, lane, crow, ni);
         });
       } else {
-        it = lm_refine(S, B.m[0][0], lane, crow, ni, prof, [&]() { lm_eval(S, lane, crow, ni, S.x, true, 0, 1); },
-                       [&]() { lm_eval(S, lane, crow, ni, S.xd, false, 5, 6); });
+        it = lm_refine(S, B.m[0][0], lane, crow, ni, prof,
+                       [&]() { if (S.fast) lm_eval_fast(S, lane, crow, ni, S.x, true, 0, 1); else lm_eval(S, lane, crow, ni, S.x, true, 0, 1); },
+                       [&]() { if (S.fast) lm_eval_fast(S, lane, crow, ni, S.xd, false, 5, 6); else lm_eval(S, lane, crow, ni, S.xd, false, 5, 6); });
       }
       pf_add(prof, PF_LM, pf_now_if(prof) - pf3); pf_add(prof, PF_LM_ITERS, it);
       if (info && lane == 0) info[2] = it;
