@@ -1251,8 +1251,9 @@ def test_tie_heavy_frame_mid_stream_reruns_on_larger_slots():
 
 
 def test_fast_solver_mode():
-    """EVH_SOLVER_FAST (include/evhip.h): LM's 8x8 systems by LDL^T instead of the operator's Jacobi eigen-solve.  The draw, the
-    masks and the refit are untouched, so statuses must be identical.  What can be asked of H, measured before the bars below
+    """EVH_SOLVER_FAST (include/evhip.h): LM's 8x8 systems by LDL^T instead of the operator's Jacobi eigen-solve, and the sums of
+    the refit and of the LM evaluations by partial sums + a tree instead of the operator's point order.  The draw and the masks
+    are untouched, so statuses must be identical.  What can be asked of H, measured before the bars below
     were written: findHomography refines on raw pixel coordinates, so J^T J is graded over 14 orders of magnitude (the
     oracle's eigen-solves on this stream: smallest eigenvalue = 5 x the truncation threshold 2 eps trace); along its weakest
     direction ANY two solvers differ in the leading digits of the step, LM is cut off after 10 iterations, and the end points
@@ -1304,6 +1305,21 @@ def test_fast_solver_mode():
         c.synchronize()
         assert np.array_equal(st.cpu().numpy(), ss)
         check(H.cpu().numpy().reshape(-1, 3, 3), Hs, ss, 1280, 720)
+    finally:
+        c.close()
+    # the reference's default detector list (SURF, SIFT, ORB): ~1 900 merged rows per pair -- where the tree-reduced sums of the
+    # tolerance mode (lm_eval_fast, dlt_rows_fast) replace the longest point-order chains
+    fr3, _ = S.make_stream(31, 9, 400, 224)
+    Hs, ss, rc = O.stream_gray_types(fr3, ["SURF", "SIFT", "ORB"])
+    c = Context(device=0, max_w=400, max_h=224, max_features=500, max_frames=len(fr3))
+    try:
+        c.sift_enable(6144); c.surf_enable(4096)
+        c.set_solver_mode(SOLVER_FAST)
+        H = torch.zeros(len(fr3) - 1, 9, dtype=torch.float64, device="cuda"); st = torch.full((len(fr3) - 1,), -1, dtype=torch.int32, device="cuda")
+        c.stream_homography_batch_types(dev(S.gray_to_bgr(fr3)), H, st, ["SURF", "SIFT", "ORB"])
+        c.synchronize()
+        assert rc == -1 and np.array_equal(st.cpu().numpy(), ss)
+        check(H.cpu().numpy().reshape(-1, 3, 3), Hs, ss, 400, 224)
     finally:
         c.close()
     print("fast solver against the oracle over %(pairs)d pairs: h_err %(h_err).2e, corners %(corner).2e px, perspective row %(abs).2e "
