@@ -796,7 +796,9 @@ __device__ __forceinline__ double wave_sum_f64_(double v) {
   for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
   return v;
 }
-__device__ __forceinline__ bool dlt_rows_fast(RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */,
+__device__ void fast_solve8(int lane, const double* A, const double* b, double* x, int* ok);
+struct SolveLds;
+__device__ __forceinline__ bool dlt_rows_fast(SolveLds& S, RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */,
                                               unsigned long long* prof) {
   double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   for (int i = lane; i < count; i += NL) {
@@ -838,6 +840,35 @@ __device__ __forceinline__ bool dlt_rows_fast(RowMat& M, int lane, const float* 
     }
   }
   WSYNC();
+  // The refit only seeds the LM refinement, so in this mode the smallest eigenvector of L^T L (117 Jacobi rotations) gives way
+  // to the inhomogeneous least-squares solution with h33 = 1 in the normalised frame: one 8x8 LDL^T.  A pivot that is not
+  // positive, or a solution that is not finite, falls back to the eigen-solve.
+  if (lane == 0) {
+    for (int i = 0; i < 8; i++) {
+      for (int j = 0; j < 8; j++) S.Ap[i * 8 + j] = M.A[i * MS + j];
+      S.tmpd[i] = -M.A[i * MS + 8];
+    }
+  }
+  WSYNC();
+  fast_solve8(lane, S.Ap, S.tmpd, S.d, &S.ib[2]);
+  WSYNC();
+  bool direct = S.ib[2] != 0;
+  if (direct) {
+    double mx = 0;
+    for (int i = 0; i < 8; i++) mx = fmax(mx, fabs(S.d[i]));
+    direct = mx < 1e12;                                   // (NaN compares false)
+  }
+  if (direct) {
+    if (lane == 0) {
+      double H0[9], H[9];
+      for (int i = 0; i < 8; i++) H0[i] = S.d[i];
+      H0[8] = 1.0;
+      dlt_finish_from(H0, cmx, cmy, smx, smy, cMx, cMy, sMx, sMy, H);
+      for (int i = 0; i < 9; i++) Hout[i] = H[i];
+    }
+    WSYNC();
+    return true;
+  }
   pf_add(prof, PF_ROT9, jacobi_one<9>(M, lane));
   if (lane == 0) {
     double H[9];
@@ -851,7 +882,7 @@ __device__ __forceinline__ bool dlt_rows_fast(RowMat& M, int lane, const float* 
 // ---- single-problem normalised DLT on `count` rows (ax,ay,bx,by): sums in row order, one lane per sum; wave 0 ------
 __device__ __forceinline__ bool dlt_rows(SolveLds& S, RowMat& M, int lane, const float* rows, int count, double* Hout /* LDS */,
                                          unsigned long long* prof = nullptr) {
-  if (S.fast && count > 4) return dlt_rows_fast(M, lane, rows, count, Hout, prof);
+  if (S.fast && count > 4) return dlt_rows_fast(S, M, lane, rows, count, Hout, prof);
   double* T = S.T;
   // centroids: lanes 0..3 own cm.x, cm.y, cM.x, cM.y  (m = b columns, M = a columns)
   double acc = 0;
