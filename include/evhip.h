@@ -140,13 +140,18 @@ enum { EVH_ORDER_CANONICAL = 0, EVH_ORDER_OPENCV = 1 };
 /* The 8x8 linear systems of findHomography's Levenberg-Marquardt refinement (matching.py:156-157, utils.py:356-358 ->
  * cv::findHomography -> LMSolver -> cv::solve(DECOMP_EIG)).
  * EVH_SOLVER_EXACT (default): the operator's own Jacobi eigen-solve, rotation by rotation in its order -- H bit-identical to the
- *   CPU restatement (and, where the consensus agrees, within 1e-7 of the reference's recorded run).
- * EVH_SOLVER_FAST: LDL^T of the same systems (a non-positive pivot falls back to the exact path).  The random draw, the
- *   inlier masks and the refit are unchanged and a stream pair costs ~45 % less (bench.py --config 3: 2.0 k -> 3.8 k pairs/s),
- *   but H is no longer OpenCV's to the digit: the systems are graded over 14 orders of magnitude (raw pixel coordinates), the
- *   loop is cut after 10 iterations, and where the data do not determine H the end points differ -- measured: frame corners
- *   up to 6e-4 px, SURVEY 8d's floored-relative h_err up to 3.6e-3 (tests/test_gpu_parity.py::test_fast_solver_mode).
- *   For callers who need the geometry, not the operator's digits. */
+ *   CPU restatement.
+ * EVH_SOLVER_EXACT (default) also means: the operator's bit-exact result on the reference's own video (all 120 recorded matrices).
+ * EVH_SOLVER_FAST ("tolerance mode"): after RANSAC -- whose random draw, hypotheses and inlier masks stay exact, so statuses are
+ *   identical -- (1) LM's 8x8 systems by LDL^T (a non-positive pivot falls back to the exact path), (2) the sums of the refit and
+ *   of the LM evaluations by per-lane partial sums and a tree instead of the operator's point order, (3) the refit itself by the
+ *   inhomogeneous least-squares solution with h33 = 1 in the normalised frame (one 8x8 LDL^T; eigen-solve as the fall-back) --
+ *   it only seeds LM.  A stream pair costs 2.5-3x less (bench.py --config 3: 2.0 k -> 5.8 k pairs/s; the reference's default
+ *   detector list at 400x224: 0.85 k -> 1.8 k), but H is no longer OpenCV's to the digit: the systems are graded over 14 orders
+ *   of magnitude (raw pixel coordinates), the loop is cut after 10 iterations, and where the data do not determine H the end
+ *   points differ -- measured over 140 pairs: frame corners up to 5.3e-4 px, SURVEY 8d's floored-relative h_err up to 2.5e-3
+ *   (tests/test_gpu_parity.py::test_fast_solver_mode; bars 5e-3 px / 2e-2).  For callers who need the geometry, not the
+ *   operator's digits. */
 enum { EVH_SOLVER_EXACT = 0, EVH_SOLVER_FAST = 1 };
 int evh_set_solver_mode(evh_ctx* ctx, int mode);
 int evh_get_solver_mode(const evh_ctx* ctx);
