@@ -1840,7 +1840,15 @@ __device__ void cv_heap_select(EP a, int first, int middle, int last, typename s
 // a range of at most CV_SMALL elements is worked on in LDS: a round then costs LDS latencies instead of a chain of
 // dependent global accesses (pivot, cut, lists), which is what the small pyramid levels and the last rounds of the large
 // ones consist of
+#ifndef CV_SMALL
 #define CV_SMALL 2048
+#endif
+#ifndef CV_MINW
+#define CV_MINW 1
+#endif
+#ifndef CV_MAXT
+#define CV_MAXT 1024
+#endif
 struct CvSmall {
   unsigned long long a[CV_SMALL];
   uint16_t l[CV_SMALL], r[CV_SMALL];
@@ -1940,7 +1948,7 @@ __device__ __forceinline__ float f32_from_order_key(uint32_t k) {
 
 // Launched twice: the large pyramid levels with 1024 threads per workgroup (a partition pass is a chain of steps, each a
 // load + a workgroup scan + stores: four times the threads = a quarter of the steps), the small ones with 256.
-__global__ __launch_bounds__(1024) void k_select_cv(SelCvArgs B) {
+__global__ __launch_bounds__(CV_MAXT, CV_MINW) void k_select_cv(SelCvArgs B) {
   const SelectArgs& A = B.s;
   __shared__ CvLds S;
   __shared__ CvSmall SM;
@@ -2401,7 +2409,8 @@ int evh_launch_select(evh_ctx* c, int nframes) {
     // more than the steps it saves; EVH_CV_SPLIT / EVH_CV_NT keep the experiment reachable)
     int split = 0, nt_small = 256;
     { const char* e = getenv("EVH_CV_SPLIT"); if (e) split = std::min(EVH_NLEVELS, std::max(0, atoi(e))); }
-    { const char* e = getenv("EVH_CV_NT"); if (e) nt_small = std::min(1024, std::max(64, atoi(e) & ~63)); }
+    { const char* e = getenv("EVH_CV_NT"); if (e) nt_small = std::min(CV_MAXT, std::max(64, atoi(e) & ~63)); }
+    if (CV_MAXT < 1024) split = 0;
     const size_t heap_bytes = sizeof(unsigned long long) * (size_t)B.heap_cap;
     if (split > 0) {
       B.level0 = 0; B.nlev = split;
