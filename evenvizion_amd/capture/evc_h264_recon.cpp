@@ -11,9 +11,9 @@ namespace evc {
 // =================================================================================================== intra 4x4 (8.3.1.2)
 void pred_intra4x4(uint8_t* dst, int stride, int mode, bool left, bool top, bool topright, bool topleft) {
     // t[-1] = p[-1,-1], t[0..7] = p[0..7,-1]; l[-1] = p[-1,-1], l[0..3] = p[-1,0..3]
-    int tbuf[9], lbuf[5];
-    int* t = tbuf + 1;
-    int* l = lbuf + 1;
+    int tbuf[10], lbuf[6];                 // (one spare slot in front: at -O3 the unrolled mode loops make the compiler
+    int* t = tbuf + 2;                     //  see subscripts it cannot prove unreachable)
+    int* l = lbuf + 2;
     if (top) {
         for (int x = 0; x < 4; ++x) t[x] = dst[-stride + x];
         if (topright)
@@ -462,51 +462,80 @@ void mc_luma(const Picture& ref, int x, int y, int mvx, int mvy, int w, int h, u
     const int W = ref.mb_w * 16, H = ref.mb_h * 16;
     const int fx = mvx & 3, fy = mvy & 3;
     const int ix = x + (mvx >> 2), iy = y + (mvy >> 2);
-    // integer samples needed: columns ix-2 .. ix+w+2, rows iy-2 .. iy+h+2
-    int tmp[21 + 1][21 + 1];
+    // integer samples needed: columns ix-2 .. ix+w+2, rows iy-2 .. iy+h+2 (clamped to the picture: 8.4.2.2.1)
+    int16_t g[21][24];
     const int tw = w + 5, th = h + 5;
-    for (int r = 0; r < th; ++r) {
-        int yy = clip3(0, H - 1, iy - 2 + r);
-        const uint8_t* row = &ref.Y[(size_t)yy * ref.stride];
-        for (int cidx = 0; cidx < tw; ++cidx) tmp[r][cidx] = row[clip3(0, W - 1, ix - 2 + cidx)];
-    }
-    auto G = [&](int xx, int yy) { return tmp[yy + 2][xx + 2]; };  // integer sample at block-relative position
-    // intermediate (unrounded) half samples
-    auto b1 = [&](int xx, int yy) {  // horizontal half sample to the right of G(xx,yy)
-        return G(xx - 2, yy) - 5 * G(xx - 1, yy) + 20 * G(xx, yy) + 20 * G(xx + 1, yy) - 5 * G(xx + 2, yy) + G(xx + 3, yy);
-    };
-    auto h1 = [&](int xx, int yy) {  // vertical half sample below G(xx,yy)
-        return G(xx, yy - 2) - 5 * G(xx, yy - 1) + 20 * G(xx, yy) + 20 * G(xx, yy + 1) - 5 * G(xx, yy + 2) + G(xx, yy + 3);
-    };
-    auto bq = [&](int xx, int yy) { return clip1((b1(xx, yy) + 16) >> 5); };
-    auto hq = [&](int xx, int yy) { return clip1((h1(xx, yy) + 16) >> 5); };
-    auto jq = [&](int xx, int yy) {  // centre half sample: 6-tap over the intermediate horizontal half samples
-        int v = b1(xx, yy - 2) - 5 * b1(xx, yy - 1) + 20 * b1(xx, yy) + 20 * b1(xx, yy + 1) - 5 * b1(xx, yy + 2) + b1(xx, yy + 3);
-        return clip1((v + 512) >> 10);
-    };
-    for (int yy = 0; yy < h; ++yy)
-        for (int xx = 0; xx < w; ++xx) {
-            int v;
-            switch (fy * 4 + fx) {
-                case 0: v = G(xx, yy); break;
-                case 1: v = (G(xx, yy) + bq(xx, yy) + 1) >> 1; break;                 // a
-                case 2: v = bq(xx, yy); break;                                          // b
-                case 3: v = (G(xx + 1, yy) + bq(xx, yy) + 1) >> 1; break;             // c
-                case 4: v = (G(xx, yy) + hq(xx, yy) + 1) >> 1; break;                 // d
-                case 5: v = (bq(xx, yy) + hq(xx, yy) + 1) >> 1; break;                // e
-                case 6: v = (bq(xx, yy) + jq(xx, yy) + 1) >> 1; break;                // f
-                case 7: v = (bq(xx, yy) + hq(xx + 1, yy) + 1) >> 1; break;            // g
-                case 8: v = hq(xx, yy); break;                                          // h
-                case 9: v = (hq(xx, yy) + jq(xx, yy) + 1) >> 1; break;                // i
-                case 10: v = jq(xx, yy); break;                                         // j
-                case 11: v = (jq(xx, yy) + hq(xx + 1, yy) + 1) >> 1; break;           // k
-                case 12: v = (G(xx, yy + 1) + hq(xx, yy) + 1) >> 1; break;            // n
-                case 13: v = (hq(xx, yy) + bq(xx, yy + 1) + 1) >> 1; break;           // p
-                case 14: v = (jq(xx, yy) + bq(xx, yy + 1) + 1) >> 1; break;           // q
-                default: v = (hq(xx + 1, yy) + bq(xx, yy + 1) + 1) >> 1; break;       // r
-            }
-            dst[yy * 16 + xx] = (uint8_t)v;
+    if (ix >= 2 && iy >= 2 && ix + w + 3 <= W && iy + h + 3 <= H) {
+        for (int r = 0; r < th; ++r) {
+            const uint8_t* row = &ref.Y[(size_t)(iy - 2 + r) * ref.stride + ix - 2];
+            for (int c = 0; c < tw; ++c) g[r][c] = row[c];
         }
+    } else {
+        for (int r = 0; r < th; ++r) {
+            const uint8_t* row = &ref.Y[(size_t)clip3(0, H - 1, iy - 2 + r) * ref.stride];
+            for (int c = 0; c < tw; ++c) g[r][c] = row[clip3(0, W - 1, ix - 2 + c)];
+        }
+    }
+    // G(xx, yy) = g[yy + 2][xx + 2].  The sixteen positions (Table 8-12) are built from three intermediate planes, each
+    // computed once per block: b1 (horizontal 6-tap, unrounded), h1 (vertical 6-tap, unrounded), j (6-tap over b1).
+    if ((fx | fy) == 0) {
+        for (int yy = 0; yy < h; ++yy)
+            for (int xx = 0; xx < w; ++xx) dst[yy * 16 + xx] = (uint8_t)g[yy + 2][xx + 2];
+        return;
+    }
+    int16_t b1[21][16];    // b1[r][xx]: horizontal half sample right of G(xx, r - 2), rows r = 0 .. h + 4
+    int16_t h1[16][17];    // h1[yy][xx]: vertical half sample below G(xx, yy), columns xx = 0 .. w
+    uint8_t bq[17][16], hq[16][17], jq[16][16];
+    const bool need_b = fx != 0, need_h = fy != 0, need_j = (fx == 2 && fy != 0) || (fy == 2 && fx != 0);
+    if (need_b) {
+        const int r0 = need_j ? 0 : 2, r1 = need_j ? th : h + 3;            // rows yy = 0 .. h (yy + 1 is used by p, q, r)
+        for (int r = r0; r < r1; ++r)
+            for (int xx = 0; xx < w; ++xx) {
+                const int16_t* q = &g[r][xx];
+                b1[r][xx] = (int16_t)(q[0] - 5 * q[1] + 20 * q[2] + 20 * q[3] - 5 * q[4] + q[5]);
+            }
+        for (int yy = 0; yy <= h; ++yy)
+            for (int xx = 0; xx < w; ++xx) bq[yy][xx] = (uint8_t)clip1((b1[yy + 2][xx] + 16) >> 5);
+    }
+    if (need_h) {
+        for (int yy = 0; yy < h; ++yy)
+            for (int xx = 0; xx <= w; ++xx) {
+                const int v = g[yy][xx + 2] - 5 * g[yy + 1][xx + 2] + 20 * g[yy + 2][xx + 2] + 20 * g[yy + 3][xx + 2] - 5 * g[yy + 4][xx + 2] + g[yy + 5][xx + 2];
+                h1[yy][xx] = (int16_t)v;
+                hq[yy][xx] = (uint8_t)clip1((v + 16) >> 5);
+            }
+    }
+    if (need_j) {
+        for (int yy = 0; yy < h; ++yy)
+            for (int xx = 0; xx < w; ++xx) {
+                const int v = b1[yy][xx] - 5 * b1[yy + 1][xx] + 20 * b1[yy + 2][xx] + 20 * b1[yy + 3][xx] - 5 * b1[yy + 4][xx] + b1[yy + 5][xx];
+                jq[yy][xx] = (uint8_t)clip1((v + 512) >> 10);
+            }
+    }
+    (void)h1;
+#define MC_LOOP(expr)                                   \
+    for (int yy = 0; yy < h; ++yy)                      \
+        for (int xx = 0; xx < w; ++xx) dst[yy * 16 + xx] = (uint8_t)(expr);
+#define GG(xx_, yy_) g[(yy_) + 2][(xx_) + 2]
+    switch (fy * 4 + fx) {
+        case 1: MC_LOOP((GG(xx, yy) + bq[yy][xx] + 1) >> 1) break;               // a
+        case 2: MC_LOOP(bq[yy][xx]) break;                                        // b
+        case 3: MC_LOOP((GG(xx + 1, yy) + bq[yy][xx] + 1) >> 1) break;           // c
+        case 4: MC_LOOP((GG(xx, yy) + hq[yy][xx] + 1) >> 1) break;               // d
+        case 5: MC_LOOP((bq[yy][xx] + hq[yy][xx] + 1) >> 1) break;               // e
+        case 6: MC_LOOP((bq[yy][xx] + jq[yy][xx] + 1) >> 1) break;               // f
+        case 7: MC_LOOP((bq[yy][xx] + hq[yy][xx + 1] + 1) >> 1) break;           // g
+        case 8: MC_LOOP(hq[yy][xx]) break;                                        // h
+        case 9: MC_LOOP((hq[yy][xx] + jq[yy][xx] + 1) >> 1) break;               // i
+        case 10: MC_LOOP(jq[yy][xx]) break;                                       // j
+        case 11: MC_LOOP((jq[yy][xx] + hq[yy][xx + 1] + 1) >> 1) break;          // k
+        case 12: MC_LOOP((GG(xx, yy + 1) + hq[yy][xx] + 1) >> 1) break;          // n
+        case 13: MC_LOOP((hq[yy][xx] + bq[yy + 1][xx] + 1) >> 1) break;          // p
+        case 14: MC_LOOP((jq[yy][xx] + bq[yy + 1][xx] + 1) >> 1) break;          // q
+        default: MC_LOOP((hq[yy][xx + 1] + bq[yy + 1][xx] + 1) >> 1) break;      // r
+    }
+#undef GG
+#undef MC_LOOP
 }
 
 // 8.4.2.2.2: chroma sample interpolation (4:2:0: the luma vector in units of 1/8 chroma sample)
@@ -515,13 +544,23 @@ void mc_chroma(const Picture& ref, int plane, int x, int y, int mvx, int mvy, in
     const std::vector<uint8_t>& pl = plane ? ref.Cr : ref.Cb;
     const int fx = mvx & 7, fy = mvy & 7;
     const int ix = x + (mvx >> 3), iy = y + (mvy >> 3);
+    const int cA = (8 - fx) * (8 - fy), cB = fx * (8 - fy), cC = (8 - fx) * fy, cD = fx * fy;
+    if (ix >= 0 && iy >= 0 && ix + w + 1 <= W && iy + h + 1 <= H) {           // wholly inside: no clamping
+        for (int yy = 0; yy < h; ++yy) {
+            const uint8_t* r0 = &pl[(size_t)(iy + yy) * ref.cstride + ix];
+            const uint8_t* r1 = r0 + ref.cstride;
+            for (int xx = 0; xx < w; ++xx)
+                dst[yy * 8 + xx] = (uint8_t)((cA * r0[xx] + cB * r0[xx + 1] + cC * r1[xx] + cD * r1[xx + 1] + 32) >> 6);
+        }
+        return;
+    }
     for (int yy = 0; yy < h; ++yy) {
         int y0 = clip3(0, H - 1, iy + yy), y1 = clip3(0, H - 1, iy + yy + 1);
         for (int xx = 0; xx < w; ++xx) {
             int x0 = clip3(0, W - 1, ix + xx), x1 = clip3(0, W - 1, ix + xx + 1);
             int A = pl[(size_t)y0 * ref.cstride + x0], B = pl[(size_t)y0 * ref.cstride + x1];
             int C = pl[(size_t)y1 * ref.cstride + x0], D = pl[(size_t)y1 * ref.cstride + x1];
-            dst[yy * 8 + xx] = (uint8_t)(((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6);
+            dst[yy * 8 + xx] = (uint8_t)((cA * A + cB * B + cC * C + cD * D + 32) >> 6);
         }
     }
 }
