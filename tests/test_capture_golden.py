@@ -191,3 +191,50 @@ def test_golden_discriminates_the_bgr_conversion():
     H, st, rc = O.stream_gray_types(g, ["SURF", "SIFT", "ORB"], Hsup_forced=golden_planes(G))
     assert (rel_err(H, G) <= 1e-3).sum() <= 15
     assert (np.abs(H - G).reshape(40, -1).max(1) == 0).sum() == 0
+
+
+def test_c_abi_argument_checks_and_end_of_stream():
+    """The C ABI refuses bad arguments with EVCAP_ERR_INVALID instead of crashing, read() keeps answering end-of-stream once the
+    frames are exhausted, the two BGR modes differ (they are two arithmetics, not a flag that is ignored), and the picture
+    planes of read_yuv420 are what read() converts."""
+    capture.build()
+    L = capture.lib()
+    L.evcap_read_bgr.restype = C.c_int
+    assert L.evcap_read_bgr(None, None, 0) < 0
+    assert L.evcap_info(None, None, None, None, None) < 0
+    h = C.c_void_p()
+    assert L.evcap_open(None, C.byref(h)) < 0 and not h
+    assert L.evcap_open(b"/nonexistent/file.mp4", None) < 0
+    data = open(MP4, "rb").read()
+    a = capture.VideoCapture(data=data)
+    b = capture.VideoCapture(MP4, bgr_mode=capture.BGR_SWSCALE_C)
+    assert a.isOpened() and b.isOpened() and (a.width, a.height) == (1170, 658)
+    ok, fa = a.read()
+    ok2, fb = b.read()
+    assert ok and ok2 and fa.shape == fb.shape == (658, 1170, 3)
+    d = np.abs(fa.astype(int) - fb.astype(int))
+    assert 0 < d.max() <= 8 and (d > 0).mean() > 0.5             # the two arithmetics are a few grey levels apart on most pixels
+    small = np.empty((658, 1170 * 3 - 1), np.uint8)              # a destination stride below the row size is refused
+    assert L.evcap_read_bgr(a._h, small.ctypes.data_as(C.c_void_p), small.strides[0]) < 0
+    c = capture.VideoCapture(MP4)
+    ok, (y, cb, cr) = c.read_yuv420()
+    assert ok and y.shape == (658, 1170) and cb.shape == cr.shape == (329, 585)
+    c2 = capture.VideoCapture(MP4)
+    ok, f0 = c2.read()
+    # the top-left pixel through the x86 arithmetic, by hand: 13-bit coefficients, pmulhw
+    def px(Y, U, V):
+        s16 = lambda v: max(-32768, min(32767, v))
+        y8, u8, v8 = (Y << 3) - 128, s16((U << 3) - 1024), s16((V << 3) - 1024)
+        Yc = (y8 * 9539) >> 16
+        cg = s16(((u8 * -3209) >> 16) + ((v8 * -6660) >> 16))
+        clip = lambda v: max(0, min(255, v))
+        return [clip(Yc + ((u8 * 16525) >> 16)), clip(Yc + cg), clip(Yc + ((v8 * 13075) >> 16))]
+    for (r, col) in ((0, 0), (1, 1), (300, 777), (657, 1169)):
+        assert f0[r, col].tolist() == px(int(y[r, col]), int(cb[r // 2, col // 2]), int(cr[r // 2, col // 2])), (r, col)
+    n = 1
+    while a.read()[0]:
+        n += 1
+    assert n == 121 and a.read() == (False, None) and a.read() == (False, None)
+    for cap in (a, b, c, c2):
+        cap.release()
+    assert not a.isOpened() and a.read() == (False, None)
